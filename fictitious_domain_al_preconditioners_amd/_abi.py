@@ -1,0 +1,84 @@
+"""ctypes mirror of include/alfd/alfd.h (structs and enums only)."""
+import ctypes as C
+
+ALFD_MAX_BLOCKS = 3
+
+# enum alfd_status
+OK, E_INVALID, E_HIP, E_NO_CONVERGENCE_OUTER, E_NO_CONVERGENCE_INNER, E_BREAKDOWN, E_NOT_SETUP, \
+    E_COMM, E_UNSUPPORTED = range(9)
+# enum alfd_matrix_slot
+A, BT, B, CT, C_, M, MP, A2, KIMM = range(9)
+NSLOTS = 9
+SLOT_BY_NAME = {"A": A, "Bt": BT, "B": B, "Ct": CT, "C": C_, "M": M, "Mp": MP, "A2": A2, "K": KIMM}
+# enum alfd_diag_slot
+INVW, MP_LUMPED_INV = 0, 1
+NDIAGS = 2
+# enum alfd_variant
+AL2, AL_STOKES, AL_STOKES_DIAG, AL_ELL_IDEAL, AL_ELL_MODIFIED, RATIONAL = range(6)
+# enum alfd_control_kind
+CTRL_ABS, CTRL_REDUCTION, CTRL_FIXED_ITERS = range(3)
+# enum alfd_inner_prec
+PREC_IDENTITY, PREC_JACOBI, PREC_CHEBYSHEV = range(3)
+# enum alfd_orthogonalization
+ORTH_MGS, ORTH_CGS, ORTH_CGS2 = range(3)
+# enum alfd_inner_failure_policy
+INNER_THROW, INNER_ACCEPT = range(2)
+# enum alfd_timing_class
+T_SPMV_A, T_SPMV_OTHER, T_DOT, T_VEC = range(4)
+T_NCLASSES = 4
+UNIQUE_ID_BYTES = 128
+
+
+class Control(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("max_steps", C.c_int32), ("tol", C.c_double), ("reduce", C.c_double)]
+
+    def __init__(self, kind=CTRL_ABS, max_steps=100, tol=1e-10, reduce=0.0):
+        super().__init__(kind, max_steps, tol, reduce)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("variant", C.c_int32), ("restart", C.c_int32), ("orthogonalization", C.c_int32),
+        ("grad_div_in_A", C.c_int32),
+        ("gamma", C.c_double), ("gamma_grad_div", C.c_double), ("gamma2", C.c_double),
+        ("outer", Control), ("inner", Control), ("mp_inner", Control),
+        ("inner_prec", C.c_int32), ("cheb_degree", C.c_int32), ("cheb_power_its", C.c_int32),
+        ("on_inner_failure", C.c_int32),
+        ("cheb_eig_ratio", C.c_double), ("cheb_safety", C.c_double),
+        ("log_level", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("outer_iterations", C.c_int32),
+        ("initial_residual", C.c_double), ("last_residual", C.c_double),
+        ("inner_iterations", C.c_int64), ("mp_iterations", C.c_int64),
+        ("inner_failures", C.c_int32), ("precond_applications", C.c_int32),
+        ("solve_seconds", C.c_double), ("lambda_max", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def default_config(variant=AL_STOKES) -> Config:
+    """Same defaults as alfd_default_config(): the reference's solver knobs
+    (parameters_stokes_3d.prm:17-24,150-157; immersed_laplace.cc:907; elliptic...:863)."""
+    c = Config()
+    c.variant = variant
+    c.restart = 50 if variant in (AL_ELL_IDEAL, AL_ELL_MODIFIED) else 30
+    c.orthogonalization = ORTH_CGS2
+    c.grad_div_in_A = 1
+    c.gamma, c.gamma_grad_div, c.gamma2 = 10.0, 10.0, 1e-2
+    c.outer = Control(CTRL_REDUCTION, 1000, 1e-8, 1e-12)
+    c.inner = Control(CTRL_ABS, 100, 1e-2, 0.0)
+    c.mp_inner = Control(CTRL_ABS, 100, 1e-6, 0.0)
+    c.inner_prec = PREC_CHEBYSHEV
+    c.cheb_degree = 4
+    c.cheb_power_its = 20
+    c.on_inner_failure = INNER_THROW
+    c.cheb_eig_ratio = 30.0
+    c.cheb_safety = 1.2
+    c.log_level = 0
+    return c

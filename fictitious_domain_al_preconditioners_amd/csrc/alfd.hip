@@ -1,0 +1,1281 @@
+// alfd.hip -- host side of libalfd.so: context, HBM-resident operators, the
+// inner PCG, the AL preconditioner vmult()s, FGMRES, and the C ABI of
+// include/alfd/alfd.h.  All arithmetic runs in the kernels of kernels.hpp; the
+// host only sequences launches and does the O(m^2) Hessenberg/Givens algebra.
+//
+// Reference objects replaced (file:line in /root/reference):
+//   * Aug = A + gamma Ct invW C                stokes_immersed_boundary.cc:991-993,
+//                                              immersed_laplace.cc:880-884
+//   * Aug_inv = inverse_operator(Aug, CG, prec) stokes...:1020-1045, immersed_laplace.cc:907-916
+//   * Mp_inv  = inverse_operator(Mp, CG(100,1e-6), lumped diag)   stokes...:931-957
+//   * BlockPreconditionerAugmentedLagrangian{,Stokes,Diagonal}::vmult
+//                                              augmented_lagrangian_preconditioner.h:28-34,62-70,95-103
+//   * AA = block_operator<..>                  stokes...:1000-1003, immersed_laplace.cc:891-892
+//   * SolverFGMRES<BlockVector<double>>::solve stokes...:1067-1074 ([EXT] deal.II 9.6 flavour)
+//   * SolverControl / ReductionControl / IterationNumberControl stop rules [EXT]
+// There is NO CPU fallback: without a HIP device every entry point fails.
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "alfd/alfd.h"
+#include "kernels.hpp"
+
+namespace alfd {
+
+// ------------------------------------------------------------------ helpers
+#define HIPC(call)                                                                          \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e__) + " (" + __FILE__ + ":" + \
+                 std::to_string(__LINE__) + ")";                                            \
+      return ALFD_E_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+#define RC(call)                  \
+  do {                            \
+    int rc__ = (call);            \
+    if (rc__ != ALFD_OK) return rc__; \
+  } while (0)
+
+static inline int64_t pad_chunk(int64_t n) { return (n + kChunk - 1) / kChunk * kChunk; }
+
+struct DevCsr {
+  bool present = false;
+  int64_t nrows = 0, ncols = 0, nnz = 0;  // local rows, global cols
+  int64_t n_list = 0;                     // rows the kernel iterates over (== nrows unless sparse)
+  bool sparse = false;
+  int L = 64;
+  int32_t n_local_cols = 0;               // columns < n_local_cols read x, others the halo
+  int64_t *rp = nullptr;
+  int32_t *col = nullptr;
+  double *val = nullptr;
+  int32_t *rows = nullptr;
+  // multi-rank halo plan
+  std::vector<int64_t> send_off, recv_off;  // per peer prefix (size nranks+1)
+  int32_t *send_idx = nullptr;              // local indices to pack
+  double *send_buf = nullptr, *halo = nullptr;
+  int64_t n_halo = 0;
+  double algorithmic_bytes() const {
+    // nnz*(8+4) + (nrows+1)*8 + nrows*8 + ncols*8  (x read once)
+    return (double)nnz * 12.0 + (double)(n_list + 1) * 8.0 + (double)n_list * 8.0 +
+           (double)(sparse ? n_list : ncols) * 8.0;
+  }
+};
+
+enum State { ITERATE = 0, SUCCESS = 1, FAILURE = 2 };
+struct Control {
+  alfd_control c;
+  double initial = 0, reduced_tol = 0, last_value = 0;
+  int last_step = 0;
+  State check(int step, double v) {
+    last_step = step;
+    last_value = v;
+    if (step == 0) {
+      initial = v;
+      reduced_tol = v * c.reduce;
+    }
+    if (c.kind == ALFD_CTRL_REDUCTION && v < reduced_tol) return SUCCESS;
+    if (c.kind == ALFD_CTRL_FIXED_ITERS && step >= c.max_steps) return SUCCESS;
+    if (v <= c.tol) return SUCCESS;
+    if (step >= c.max_steps || std::isnan(v)) return FAILURE;
+    return ITERATE;
+  }
+};
+
+struct TimedLaunch {
+  int cls;
+  hipEvent_t a, b;
+};
+
+}  // namespace alfd
+
+using namespace alfd;
+
+struct alfd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // partition / comm
+  int rank = 0, nranks = 1;
+  ncclComm_t nccl = nullptr;
+  std::vector<std::vector<int64_t>> part;  // [block][nranks+1] global offsets
+  // layout
+  int nblocks = 0;
+  int64_t n[ALFD_MAX_BLOCKS] = {0, 0, 0};        // local block lengths
+  int64_t off[ALFD_MAX_BLOCKS + 1] = {0, 0, 0, 0};  // padded local offsets
+  int64_t nmax = 0;                               // max padded block length
+  DevCsr mat[ALFD_NSLOTS];
+  double *diag[ALFD_NDIAGS] = {nullptr, nullptr};
+  int64_t diag_n[ALFD_NDIAGS] = {0, 0};
+  alfd_config cfg;
+  bool configured = false, is_setup = false;
+  // device workspace
+  double *sc = nullptr;        // device scalar table
+  double *sc_host = nullptr;   // pinned mirror
+  double *partial = nullptr;   // dot partials [(kMaxBasis+2) * pstride]
+  int64_t pstride = 0;
+  double *gather = nullptr;    // multi-rank scalar all-gather buffer
+  double *dinv_aug = nullptr, *dA = nullptr, *s_aug = nullptr;
+  double *w_r = nullptr, *w_z = nullptr, *w_p = nullptr, *w_Ap = nullptr;  // PCG
+  double *c_d = nullptr, *c_res = nullptr, *c_tmp = nullptr;               // Chebyshev
+  double *t_lam = nullptr;                                                 // invW .* (C x)
+  double *q_tmp = nullptr, *rhs_tmp = nullptr;                             // precond scratch
+  double *V = nullptr, *Z = nullptr, *xb = nullptr, *bb = nullptr, *io = nullptr;
+  double lambda_max = 0, lambda_min = 0;
+  // stats of the current solve
+  int64_t inner_its = 0, mp_its = 0;
+  int inner_failures = 0, precond_applications = 0;
+  std::vector<double> history;
+  // timing
+  bool timing = false;
+  std::vector<TimedLaunch> timed;
+  double t_ms[ALFD_T_NCLASSES] = {0, 0, 0, 0};
+  int64_t t_launches[ALFD_T_NCLASSES] = {0, 0, 0, 0};
+  double t_bytes[ALFD_T_NCLASSES] = {0, 0, 0, 0};
+  std::vector<void *> allocs;
+  int64_t ntot() const { return off[nblocks]; }
+};
+
+namespace alfd {
+
+template <class T>
+static int dev_alloc(alfd_ctx *ctx, T **p, int64_t count) {
+  void *q = nullptr;
+  HIPC(hipMalloc(&q, std::max<int64_t>(count, 1) * sizeof(T)));
+  ctx->allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return ALFD_OK;
+}
+static int dev_alloc_zero(alfd_ctx *ctx, double **p, int64_t count) {
+  RC(dev_alloc(ctx, p, count));
+  HIPC(hipMemsetAsync(*p, 0, std::max<int64_t>(count, 1) * sizeof(double), ctx->stream));
+  return ALFD_OK;
+}
+
+static inline int grid_for_rows(int64_t nrows, int L) {
+  const int64_t groups = (nrows + (kBlock / L) - 1) / (kBlock / L);
+  // 256 CUs x 8 resident 256-thread workgroups; grid-stride beyond that
+  return (int)std::max<int64_t>(1, std::min<int64_t>(groups, 256 * 8));
+}
+
+struct Timer {
+  alfd_ctx *ctx;
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timer(alfd_ctx *c, int cl, double bytes) : ctx(c), cls(cl) {
+    if (ctx->timing) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, ctx->stream);
+      ctx->t_bytes[cls] += bytes;
+      ctx->t_launches[cls]++;
+    }
+  }
+  ~Timer() {
+    if (ctx->timing) {
+      hipEventRecord(b, ctx->stream);
+      ctx->timed.push_back({cls, a, b});
+    }
+  }
+};
+
+static void flush_timers(alfd_ctx *ctx) {
+  for (auto &t : ctx->timed) {
+    hipEventSynchronize(t.b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, t.a, t.b);
+    ctx->t_ms[t.cls] += ms;
+    hipEventDestroy(t.a);
+    hipEventDestroy(t.b);
+  }
+  ctx->timed.clear();
+}
+
+// ------------------------------------------------------------------- SpMV
+template <int L>
+static void launch_spmv_L(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
+                          const double *d, double *y2) {
+  const int grid = grid_for_rows(m.n_list, L);
+  const double *xh = m.halo;
+#define ALFD_SPMV(EPI, SP)                                                                          \
+  hipLaunchKernelGGL((spmv_kernel<L, EPI, SP>), dim3(grid), dim3(kBlock), 0, ctx->stream, m.n_list, \
+                     m.rp, m.col, m.val, m.rows, x, xh, m.n_local_cols, y, alpha, d, y2)
+  if (m.sparse) {
+    if (epi == 0) ALFD_SPMV(0, true);
+    else if (epi == 1) ALFD_SPMV(1, true);
+    else if (epi == 2) ALFD_SPMV(2, true);
+    else ALFD_SPMV(3, true);
+  } else {
+    if (epi == 0) ALFD_SPMV(0, false);
+    else if (epi == 1) ALFD_SPMV(1, false);
+    else if (epi == 2) ALFD_SPMV(2, false);
+    else ALFD_SPMV(3, false);
+  }
+#undef ALFD_SPMV
+}
+
+static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x);
+
+// epi 0: y = A x; 1: y = fma(alpha, A x, y); 2: y = d .* (A x); 3: y = A x, y2 = d .* y
+static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, double alpha = 0.0,
+                const double *d = nullptr, double *y2 = nullptr) {
+  DevCsr &m = ctx->mat[slot];
+  if (!m.present) return ctx->err = "matrix slot " + std::to_string(slot) + " not set", ALFD_E_NOT_SETUP;
+  if (ctx->nranks > 1 && (m.n_halo > 0 || m.send_off.back() > 0)) RC(halo_exchange(ctx, m, x));
+  if (m.sparse && epi != 1) {
+    // rows outside the list are structurally empty: their result is 0
+    HIPC(hipMemsetAsync(y, 0, m.nrows * sizeof(double), ctx->stream));
+    if (epi == 3) HIPC(hipMemsetAsync(y2, 0, m.nrows * sizeof(double), ctx->stream));
+  }
+  if (m.n_list == 0) return ALFD_OK;
+  Timer tm(ctx, slot == ALFD_A ? ALFD_T_SPMV_A : ALFD_T_SPMV_OTHER, m.algorithmic_bytes());
+  switch (m.L) {
+    case 4: launch_spmv_L<4>(ctx, m, x, y, epi, alpha, d, y2); break;
+    case 8: launch_spmv_L<8>(ctx, m, x, y, epi, alpha, d, y2); break;
+    case 16: launch_spmv_L<16>(ctx, m, x, y, epi, alpha, d, y2); break;
+    case 32: launch_spmv_L<32>(ctx, m, x, y, epi, alpha, d, y2); break;
+    default: launch_spmv_L<64>(ctx, m, x, y, epi, alpha, d, y2); break;
+  }
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+// ------------------------------------------------------------ reductions
+// count dots whose chunk partials sit at partial[j*pstride ..]; results land in
+// sc[out+j] (single rank) with optional PCG post-op.
+static int finish_dots(alfd_ctx *ctx, int64_t nb, int count, int out, int fin) {
+  if (ctx->nranks == 1) {
+    hipLaunchKernelGGL(dot_final_kernel, dim3(count), dim3(kBlock), 0, ctx->stream, ctx->partial, nb,
+                       ctx->pstride, ctx->sc, out, fin);
+    HIPC(hipGetLastError());
+    return ALFD_OK;
+  }
+  // multi-rank: local sums -> all-gather -> ordered sum (rank 0 first); the
+  // PCG post-ops are applied by a tiny follow-up kernel on every rank.
+  hipLaunchKernelGGL(dot_final_kernel, dim3(count), dim3(kBlock), 0, ctx->stream, ctx->partial, nb,
+                     ctx->pstride, ctx->sc, (int)S_STAGE, (int)FIN_STORE);
+  HIPC(hipGetLastError());
+  if (ncclAllGather(ctx->sc + S_STAGE, ctx->gather, count, ncclDouble, ctx->nccl, ctx->stream) !=
+      ncclSuccess)
+    return ctx->err = "ncclAllGather failed", ALFD_E_COMM;
+  const int tgt = fin == FIN_STORE ? out : (int)S_TMP;
+  hipLaunchKernelGGL(rank_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->gather, ctx->nranks, count,
+                     ctx->sc, tgt);
+  if (fin != FIN_STORE) {
+    // re-run the post-op on the summed value: a 1-chunk "partial" == the value
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->sc + S_TMP,
+                       (int64_t)1, (int64_t)0, ctx->sc, out, fin);
+  }
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+static int dot_async(alfd_ctx *ctx, int64_t npad, const double *x, const double *y, int out,
+                     int fin = FIN_STORE) {
+  const int64_t nb = npad / kChunk;
+  {
+    Timer tm(ctx, ALFD_T_DOT, 16.0 * npad);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream, x, y,
+                       ctx->partial);
+  }
+  HIPC(hipGetLastError());
+  return finish_dots(ctx, nb, 1, out, fin);
+}
+
+static int read_scalars(alfd_ctx *ctx, int first, int count) {
+  HIPC(hipMemcpyAsync(ctx->sc_host + first, ctx->sc + first, count * sizeof(double), hipMemcpyDeviceToHost,
+                      ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  return ALFD_OK;
+}
+
+#define VEC_LAUNCH(kernel, npad, bytes_per_elem, ...)                                              \
+  do {                                                                                             \
+    Timer tm__(ctx, ALFD_T_VEC, (double)(bytes_per_elem) * (double)(npad));                        \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((npad) / kChunk)), dim3(kBlock), 0, ctx->stream,    \
+                       __VA_ARGS__);                                                               \
+  } while (0)
+
+// ------------------------------------------------------------- operators
+// y = A x + gamma Ct (invW .* (C x))
+static int aug_apply(alfd_ctx *ctx, const double *x, double *y) {
+  RC(spmv(ctx, ALFD_A, x, y, 0));
+  RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 2, 0.0, ctx->diag[ALFD_INVW]));
+  RC(spmv(ctx, ALFD_CT, ctx->t_lam, y, 1, ctx->cfg.gamma));
+  return ALFD_OK;
+}
+
+enum OpKind { OP_AUG = 0, OP_MP = 1 };
+static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y) {
+  return op == OP_AUG ? aug_apply(ctx, x, y) : spmv(ctx, ALFD_MP, x, y, 0);
+}
+
+// Chebyshev sweep z = p_k(D^-1 Aug) D^-1 r
+static int cheb_apply(alfd_ctx *ctx, const double *r, double *z, int64_t npad) {
+  const double lmax = ctx->lambda_max, lmin = ctx->lambda_min;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  const int k = ctx->cfg.cheb_degree;
+  VEC_LAUNCH(cheb_init_kernel, npad, k > 1 ? 40 : 32, 1.0 / theta, ctx->dinv_aug, r, ctx->c_d, z,
+             ctx->c_res, k > 1 ? 1 : 0);
+  for (int j = 1; j < k; ++j) {
+    RC(aug_apply(ctx, ctx->c_d, ctx->c_tmp));
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    VEC_LAUNCH(cheb_step_kernel, npad, 64, c1, c2, ctx->dinv_aug, ctx->c_tmp, ctx->c_res, ctx->c_d, z);
+    rho = rho_new;
+  }
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+// deal.II SolverCG via inverse_operator (zero initial guess) [EXT]; b and x are
+// padded device vectors of block `blk`.
+static int pcg(alfd_ctx *ctx, int op, int prec, const double *dinv, const alfd_control &ctrl,
+               const double *b, double *x, int blk, int *its_out, State *st_out, double *res_out) {
+  const int64_t npad = pad_chunk(ctx->n[blk]);
+  const int64_t nb = npad / kChunk;
+  double *r = ctx->w_r, *z = ctx->w_z, *p = ctx->w_p, *Ap = ctx->w_Ap;
+  HIPC(hipMemcpyAsync(r, b, npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPC(hipMemsetAsync(x, 0, npad * sizeof(double), ctx->stream));
+  // SpMV writes rows only: the padding tail of Ap may hold data of a previous,
+  // longer solve and must be zero for the fused r-update / dot kernels.
+  if (npad > ctx->n[blk])
+    HIPC(hipMemsetAsync(Ap + ctx->n[blk], 0, (npad - ctx->n[blk]) * sizeof(double), ctx->stream));
+  Control sc{ctrl};
+  RC(dot_async(ctx, npad, r, r, S_RR));
+  RC(read_scalars(ctx, S_RR, 1));
+  double res = std::sqrt(ctx->sc_host[S_RR]);
+  State st = sc.check(0, res);
+  int its = 0;
+  while (st == ITERATE) {
+    ++its;
+    const double *zz = z;
+    if (prec == ALFD_PREC_IDENTITY) {
+      zz = r;
+      RC(dot_async(ctx, npad, r, r, 0, FIN_RZ));
+    } else if (prec == ALFD_PREC_JACOBI) {
+      VEC_LAUNCH(jacobi_dot_kernel, npad, 24, dinv, r, z, ctx->partial);
+      RC(finish_dots(ctx, nb, 1, 0, FIN_RZ));
+    } else {
+      RC(cheb_apply(ctx, r, z, npad));
+      RC(dot_async(ctx, npad, r, z, 0, FIN_RZ));
+    }
+    VEC_LAUNCH(p_update_kernel, npad, its == 1 ? 16 : 24, ctx->sc, its == 1 ? 1 : 0, zz, p);
+    RC(op_apply(ctx, op, p, Ap));
+    RC(dot_async(ctx, npad, p, Ap, 0, FIN_ALPHA));
+    VEC_LAUNCH(xr_update_dot_kernel, npad, 48, ctx->sc, p, Ap, x, r, ctx->partial);
+    RC(finish_dots(ctx, nb, 1, S_RR, FIN_STORE));
+    RC(read_scalars(ctx, S_RR, 1));
+    res = std::sqrt(ctx->sc_host[S_RR]);
+    st = sc.check(its, res);
+  }
+  *its_out = its;
+  *st_out = st;
+  *res_out = res;
+  return ALFD_OK;
+}
+
+static int inner_status(alfd_ctx *ctx, State st, double res) {
+  if (st == FAILURE) {
+    if (std::isnan(res)) return ctx->err = "inner CG breakdown (NaN)", ALFD_E_BREAKDOWN;
+    if (ctx->cfg.on_inner_failure == ALFD_INNER_THROW)
+      return ctx->err = "inner CG did not converge (SolverControl::NoConvergence)",
+             ALFD_E_NO_CONVERGENCE_INNER;
+    ctx->inner_failures++;
+  }
+  return ALFD_OK;
+}
+
+static int inner_solve_aug(alfd_ctx *ctx, const double *b, double *x) {
+  int its = 0;
+  State st;
+  double res;
+  RC(pcg(ctx, OP_AUG, ctx->cfg.inner_prec, ctx->dinv_aug, ctx->cfg.inner, b, x, 0, &its, &st, &res));
+  ctx->inner_its += its;
+  if (ctx->cfg.log_level >= 3 && ctx->rank == 0) std::printf("DEAL:aug:cg::%s step %d value %.17g\n", st == SUCCESS ? "Convergence" : "Failure", its, res);
+  return inner_status(ctx, st, res);
+}
+static int inner_solve_mp(alfd_ctx *ctx, const double *b, double *x) {
+  int its = 0;
+  State st;
+  double res;
+  RC(pcg(ctx, OP_MP, ALFD_PREC_JACOBI, ctx->diag[ALFD_MP_LUMPED_INV], ctx->cfg.mp_inner, b, x, 1, &its,
+         &st, &res));
+  ctx->mp_its += its;
+  if (ctx->cfg.log_level >= 3 && ctx->rank == 0) std::printf("DEAL:mp:cg::%s step %d value %.17g\n", st == SUCCESS ? "Convergence" : "Failure", its, res);
+  return inner_status(ctx, st, res);
+}
+
+// Preconditioner vmult on padded device block vectors.
+static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
+  ctx->precond_applications++;
+  const alfd_config &c = ctx->cfg;
+  const double *w = ctx->diag[ALFD_INVW];
+  const int64_t *off = ctx->off;
+  if (c.variant == ALFD_AL2) {
+    // augmented_lagrangian_preconditioner.h:28-34
+    const int64_t n1p = pad_chunk(ctx->n[1]), n0p = pad_chunk(ctx->n[0]);
+    VEC_LAUNCH(pmul_scale_kernel, n1p, 24, -c.gamma, w, u + off[1], v + off[1]);
+    HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
+                        ctx->stream));
+    RC(spmv(ctx, ALFD_CT, v + off[1], ctx->rhs_tmp, 1, -1.0));
+    return inner_solve_aug(ctx, ctx->rhs_tmp, v + off[0]);
+  }
+  if (c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG) {
+    // :62-70 (block triangular) / :95-103 (block diagonal SPD)
+    const bool tri = c.variant == ALFD_AL_STOKES;
+    const double sgn = tri ? -1.0 : 1.0;
+    const int64_t n0p = pad_chunk(ctx->n[0]), n1p = pad_chunk(ctx->n[1]), n2p = pad_chunk(ctx->n[2]);
+    VEC_LAUNCH(pmul_scale_kernel, n2p, 24, sgn * c.gamma, w, u + off[2], v + off[2]);
+    RC(inner_solve_mp(ctx, u + off[1], ctx->q_tmp));
+    VEC_LAUNCH(scale_copy_kernel, n1p, 16, sgn * c.gamma_grad_div, ctx->q_tmp, v + off[1]);
+    HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
+                        ctx->stream));
+    if (tri) {
+      RC(spmv(ctx, ALFD_BT, v + off[1], ctx->rhs_tmp, 1, -1.0));
+      RC(spmv(ctx, ALFD_CT, v + off[2], ctx->rhs_tmp, 1, -1.0));
+    }
+    return inner_solve_aug(ctx, ctx->rhs_tmp, v + off[0]);
+  }
+  return ctx->err = "preconditioner variant not implemented yet", ALFD_E_UNSUPPORTED;
+}
+
+// AA.vmult on padded device block vectors.
+static int system_apply(alfd_ctx *ctx, const double *x, double *y) {
+  const alfd_config &c = ctx->cfg;
+  const int64_t *off = ctx->off;
+  const int last = ctx->nblocks - 1;
+  if (c.variant == ALFD_AL2 || c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG) {
+    const double *x0 = x + off[0];
+    double *y0 = y + off[0];
+    RC(spmv(ctx, ALFD_A, x0, y0, 0));
+    RC(spmv(ctx, ALFD_C, x0, y + off[last], 3, 0.0, ctx->diag[ALFD_INVW], ctx->t_lam));
+    RC(spmv(ctx, ALFD_CT, ctx->t_lam, y0, 1, c.gamma));
+    if (ctx->nblocks == 3) {
+      RC(spmv(ctx, ALFD_BT, x + off[1], y0, 1, 1.0));
+      RC(spmv(ctx, ALFD_B, x0, y + off[1], 0));
+    }
+    RC(spmv(ctx, ALFD_CT, x + off[last], y0, 1, 1.0));
+    return ALFD_OK;
+  }
+  return ctx->err = "system operator variant not implemented yet", ALFD_E_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------- FGMRES
+static int block_dots(alfd_ctx *ctx, const double *Vb, int count, const double *w, int out) {
+  const int64_t N = ctx->ntot(), nb = N / kChunk;
+  {
+    Timer tm(ctx, ALFD_T_DOT, 8.0 * N * (count + 1));
+    hipLaunchKernelGGL(multi_dot_partial_kernel, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream, Vb, N,
+                       count, w, ctx->partial, ctx->pstride);
+  }
+  HIPC(hipGetLastError());
+  return finish_dots(ctx, nb, count, out, FIN_STORE);
+}
+
+static int fgmres(alfd_ctx *ctx, alfd_result *out) {
+  const alfd_config &c = ctx->cfg;
+  const int m = c.restart;
+  const int64_t N = ctx->ntot();
+  double *x = ctx->xb, *b = ctx->bb;
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), h(m + 2), h2(m + 2), y(m);
+  Control sc{c.outer};
+  int k = 0;
+  State st = ITERATE;
+  double res = 0;
+  ctx->history.clear();
+  auto Vj = [&](int j) { return ctx->V + (int64_t)j * N; };
+  auto Zj = [&](int j) { return ctx->Z + (int64_t)j * N; };
+  do {
+    RC(system_apply(ctx, x, Vj(0)));
+    VEC_LAUNCH(sub_from_kernel, N, 24, b, Vj(0));
+    RC(dot_async(ctx, N, Vj(0), Vj(0), S_TMP));
+    RC(read_scalars(ctx, S_TMP, 1));
+    res = std::sqrt(ctx->sc_host[S_TMP]);
+    st = sc.check(k, res);
+    if (k == 0) ctx->history.push_back(res);
+    if (c.log_level >= 2 && ctx->rank == 0) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
+    if (st != ITERATE) break;
+    if (res != 0.0) VEC_LAUNCH(scale_kernel, N, 16, (const double *)nullptr, 0, 0, 1.0 / res, Vj(0));
+    g[0] = res;
+    int j = 0;
+    for (; j < m && st == ITERATE; ++j) {
+      RC(precond_apply(ctx, Vj(j), Zj(j)));
+      double *wv = Vj(j + 1);
+      RC(system_apply(ctx, Zj(j), wv));
+      if (c.orthogonalization == ALFD_ORTH_MGS) {
+        for (int i = 0; i <= j; ++i) {
+          RC(dot_async(ctx, N, Vj(i), wv, S_H + i));
+          hipLaunchKernelGGL(multi_axpy_neg_kernel, dim3((unsigned)(N / kChunk)), dim3(kBlock), 0,
+                             ctx->stream, Vj(i), N, 1, ctx->sc, (int)S_H + i, wv);
+        }
+        RC(read_scalars(ctx, S_H, j + 1));
+        for (int i = 0; i <= j; ++i) h[i] = ctx->sc_host[S_H + i];
+      } else {
+        RC(block_dots(ctx, ctx->V, j + 1, wv, S_H));
+        VEC_LAUNCH(multi_axpy_neg_kernel, N, 8.0 * (j + 3), ctx->V, N, j + 1, ctx->sc, (int)S_H, wv);
+        if (c.orthogonalization == ALFD_ORTH_CGS2) {
+          RC(block_dots(ctx, ctx->V, j + 1, wv, S_H + kMaxBasis));
+          VEC_LAUNCH(multi_axpy_neg_kernel, N, 8.0 * (j + 3), ctx->V, N, j + 1, ctx->sc,
+                     (int)S_H + kMaxBasis, wv);
+          RC(read_scalars(ctx, S_H, 2 * kMaxBasis));
+          for (int i = 0; i <= j; ++i) h[i] = ctx->sc_host[S_H + i] + ctx->sc_host[S_H + kMaxBasis + i];
+        } else {
+          RC(read_scalars(ctx, S_H, j + 1));
+          for (int i = 0; i <= j; ++i) h[i] = ctx->sc_host[S_H + i];
+        }
+      }
+      RC(dot_async(ctx, N, wv, wv, S_TMP));
+      RC(read_scalars(ctx, S_TMP, 1));
+      h[j + 1] = std::sqrt(ctx->sc_host[S_TMP]);
+      if (h[j + 1] != 0.0)
+        VEC_LAUNCH(scale_kernel, N, 16, (const double *)nullptr, 0, 0, 1.0 / h[j + 1], wv);
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * h[i] + sn[i] * h[i + 1];
+        h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+        h[i] = t;
+      }
+      const double denom = std::sqrt(h[j] * h[j] + h[j + 1] * h[j + 1]);
+      cs[j] = h[j] / denom;
+      sn[j] = h[j + 1] / denom;
+      h[j] = denom;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h[i];
+      res = std::fabs(g[j + 1]);
+      ++k;
+      st = sc.check(k, res);
+      ctx->history.push_back(res);
+      if (c.log_level >= 2 && ctx->rank == 0) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
+    }
+    for (int i = j - 1; i >= 0; --i) {
+      double s = g[i];
+      for (int l = i + 1; l < j; ++l) s -= H[(size_t)i * m + l] * y[l];
+      y[i] = s / H[(size_t)i * m + i];
+    }
+    for (int i = 0; i < j; ++i) ctx->sc_host[S_H + i] = y[i];
+    HIPC(hipMemcpyAsync(ctx->sc + S_H, ctx->sc_host + S_H, j * sizeof(double), hipMemcpyHostToDevice,
+                        ctx->stream));
+    VEC_LAUNCH(multi_axpy_kernel, N, 8.0 * (j + 2), ctx->Z, N, j, ctx->sc, (int)S_H, x);
+    HIPC(hipStreamSynchronize(ctx->stream));  // sc_host is reused next cycle
+  } while (st == ITERATE);
+  out->outer_iterations = k;
+  out->initial_residual = sc.initial;
+  out->last_residual = res;
+  if (c.log_level >= 1 && ctx->rank == 0)
+    std::printf(st == SUCCESS ? "DEAL:FGMRES::Convergence step %d value %.17g\n"
+                              : "DEAL:FGMRES::Failure step %d value %.17g\n",
+                k, res);
+  if (st != SUCCESS) {
+    ctx->err = "FGMRES did not converge (SolverControl::NoConvergence)";
+    return std::isnan(res) ? ALFD_E_BREAKDOWN : ALFD_E_NO_CONVERGENCE_OUTER;
+  }
+  return ALFD_OK;
+}
+
+// ---------------------------------------------------------------- halo
+static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x) {
+  const int64_t nsend = m.send_off.back();
+  if (nsend > 0) {
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((nsend + 255) / 256)), dim3(256), 0, ctx->stream,
+                       nsend, m.send_idx, x, m.send_buf);
+    HIPC(hipGetLastError());
+  }
+  if (ncclGroupStart() != ncclSuccess) return ctx->err = "ncclGroupStart", ALFD_E_COMM;
+  for (int p = 0; p < ctx->nranks; ++p) {
+    const int64_t ns = m.send_off[p + 1] - m.send_off[p], nr = m.recv_off[p + 1] - m.recv_off[p];
+    if (ns > 0 && ncclSend(m.send_buf + m.send_off[p], ns, ncclDouble, p, ctx->nccl, ctx->stream) != ncclSuccess)
+      return ctx->err = "ncclSend", ALFD_E_COMM;
+    if (nr > 0 && ncclRecv(m.halo + m.recv_off[p], nr, ncclDouble, p, ctx->nccl, ctx->stream) != ncclSuccess)
+      return ctx->err = "ncclRecv", ALFD_E_COMM;
+  }
+  if (ncclGroupEnd() != ncclSuccess) return ctx->err = "ncclGroupEnd", ALFD_E_COMM;
+  return ALFD_OK;
+}
+
+// Which vector blocks a slot maps between: {row block, col block}; -1 = last.
+static void slot_blocks(const alfd_ctx *ctx, int slot, int *rb, int *cb) {
+  const int last = ctx->nblocks - 1;
+  switch (slot) {
+    case ALFD_A: *rb = 0, *cb = 0; break;
+    case ALFD_BT: *rb = 0, *cb = 1; break;
+    case ALFD_B: *rb = 1, *cb = 0; break;
+    case ALFD_CT: *rb = 0, *cb = last; break;
+    case ALFD_C: *rb = last, *cb = 0; break;
+    case ALFD_M: *rb = last, *cb = last; break;
+    case ALFD_MP: *rb = 1, *cb = 1; break;
+    case ALFD_A2: *rb = 1, *cb = 1; break;
+    default: *rb = last, *cb = last; break;
+  }
+}
+
+static void choose_lanes(DevCsr &m, int64_t nonempty) {
+  const double avg = nonempty ? (double)m.nnz / (double)nonempty : 0.0;
+  if (avg > 48) m.L = 64;
+  else if (avg > 24) m.L = 32;
+  else if (avg > 12) m.L = 16;
+  else if (avg > 6) m.L = 8;
+  else m.L = 4;
+}
+
+static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, const int64_t *rp,
+                         const int32_t *col, const double *val) {
+  DevCsr &m = ctx->mat[slot];
+  m = DevCsr();
+  m.nrows = nrows;
+  m.ncols = ncols;
+  m.nnz = rp[nrows];
+  int64_t nonempty = 0;
+  for (int64_t r = 0; r < nrows; ++r) nonempty += rp[r + 1] > rp[r];
+  choose_lanes(m, nonempty);
+  m.sparse = nonempty * 2 < nrows;
+  const int32_t *col_up = col;
+  std::vector<int32_t> remap;
+  m.n_local_cols = (int32_t)ncols;
+  if (ctx->nranks > 1) {
+    if (ctx->part.empty()) return ctx->err = "alfd_set_partition must precede alfd_set_matrix", ALFD_E_INVALID;
+    int rb, cb;
+    slot_blocks(ctx, slot, &rb, &cb);
+    const std::vector<int64_t> &po = ctx->part[cb];
+    const int64_t c0 = po[ctx->rank], c1 = po[ctx->rank + 1];
+    m.n_local_cols = (int32_t)(c1 - c0);
+    // off-rank columns, sorted unique (ascending global => grouped by owner)
+    std::vector<int32_t> hal;
+    for (int64_t k = 0; k < m.nnz; ++k)
+      if (col[k] < c0 || col[k] >= c1) hal.push_back(col[k]);
+    std::sort(hal.begin(), hal.end());
+    hal.erase(std::unique(hal.begin(), hal.end()), hal.end());
+    m.n_halo = (int64_t)hal.size();
+    remap.resize(m.nnz);
+    for (int64_t k = 0; k < m.nnz; ++k) {
+      const int32_t c = col[k];
+      if (c >= c0 && c < c1)
+        remap[k] = (int32_t)(c - c0);
+      else
+        remap[k] = m.n_local_cols + (int32_t)(std::lower_bound(hal.begin(), hal.end(), c) - hal.begin());
+    }
+    col_up = remap.data();
+    // receive plan: halo entries grouped by owner; send plan obtained by
+    // exchanging the requested global ids (host side, via RCCL on int32).
+    m.recv_off.assign(ctx->nranks + 1, 0);
+    for (int32_t c : hal) {
+      const int owner = (int)(std::upper_bound(po.begin(), po.end(), (int64_t)c) - po.begin()) - 1;
+      m.recv_off[owner + 1]++;
+    }
+    for (int p = 0; p < ctx->nranks; ++p) m.recv_off[p + 1] += m.recv_off[p];
+    // counts all-to-all through an all-gather of the nranks x nranks matrix
+    std::vector<int32_t> cnt_local(ctx->nranks), cnt_all((size_t)ctx->nranks * ctx->nranks);
+    for (int p = 0; p < ctx->nranks; ++p) cnt_local[p] = (int32_t)(m.recv_off[p + 1] - m.recv_off[p]);
+    int32_t *d_cl = nullptr, *d_ca = nullptr;
+    RC(dev_alloc(ctx, &d_cl, ctx->nranks));
+    RC(dev_alloc(ctx, &d_ca, (int64_t)ctx->nranks * ctx->nranks));
+    HIPC(hipMemcpyAsync(d_cl, cnt_local.data(), ctx->nranks * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (ncclAllGather(d_cl, d_ca, ctx->nranks, ncclInt32, ctx->nccl, ctx->stream) != ncclSuccess)
+      return ctx->err = "ncclAllGather(counts)", ALFD_E_COMM;
+    HIPC(hipMemcpyAsync(cnt_all.data(), d_ca, cnt_all.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    m.send_off.assign(ctx->nranks + 1, 0);
+    for (int p = 0; p < ctx->nranks; ++p)
+      m.send_off[p + 1] = m.send_off[p] + cnt_all[(size_t)p * ctx->nranks + ctx->rank];
+    const int64_t nsend = m.send_off.back();
+    // exchange requested ids: I send my halo id list slices, receive what peers want from me
+    int32_t *d_req = nullptr, *d_want = nullptr;
+    RC(dev_alloc(ctx, &d_req, m.n_halo));
+    RC(dev_alloc(ctx, &d_want, nsend));
+    HIPC(hipMemcpyAsync(d_req, hal.data(), m.n_halo * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (ncclGroupStart() != ncclSuccess) return ctx->err = "ncclGroupStart", ALFD_E_COMM;
+    for (int p = 0; p < ctx->nranks; ++p) {
+      const int64_t nr = m.recv_off[p + 1] - m.recv_off[p], ns = m.send_off[p + 1] - m.send_off[p];
+      if (nr > 0) ncclSend(d_req + m.recv_off[p], nr, ncclInt32, p, ctx->nccl, ctx->stream);
+      if (ns > 0) ncclRecv(d_want + m.send_off[p], ns, ncclInt32, p, ctx->nccl, ctx->stream);
+    }
+    if (ncclGroupEnd() != ncclSuccess) return ctx->err = "ncclGroupEnd", ALFD_E_COMM;
+    std::vector<int32_t> want(nsend);
+    HIPC(hipMemcpyAsync(want.data(), d_want, nsend * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    // the column space of this matrix is block cb; my owned range there starts at c0
+    for (auto &g : want) g = (int32_t)(g - c0);
+    RC(dev_alloc(ctx, &m.send_idx, nsend));
+    HIPC(hipMemcpyAsync(m.send_idx, want.data(), nsend * 4, hipMemcpyHostToDevice, ctx->stream));
+    RC(dev_alloc(ctx, &m.send_buf, nsend));
+    RC(dev_alloc(ctx, &m.halo, m.n_halo));
+    HIPC(hipStreamSynchronize(ctx->stream));
+  }
+  RC(dev_alloc(ctx, &m.col, m.nnz));
+  RC(dev_alloc(ctx, &m.val, m.nnz));
+  HIPC(hipMemcpyAsync(m.col, col_up, m.nnz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(m.val, val, m.nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (m.sparse) {
+    std::vector<int32_t> rows;
+    std::vector<int64_t> crp(1, 0);
+    for (int64_t r = 0; r < nrows; ++r)
+      if (rp[r + 1] > rp[r]) {
+        rows.push_back((int32_t)r);
+        crp.push_back(rp[r + 1]);
+      }
+    // compact row pointer: entries of non-empty rows are contiguous in CSR order
+    for (size_t i = 0; i < rows.size(); ++i) crp[i] = rp[rows[i]];
+    crp[rows.size()] = m.nnz;
+    m.n_list = (int64_t)rows.size();
+    RC(dev_alloc(ctx, &m.rows, m.n_list));
+    RC(dev_alloc(ctx, &m.rp, m.n_list + 1));
+    HIPC(hipMemcpyAsync(m.rows, rows.data(), m.n_list * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipMemcpyAsync(m.rp, crp.data(), (m.n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                        ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+  } else {
+    m.n_list = nrows;
+    RC(dev_alloc(ctx, &m.rp, nrows + 1));
+    HIPC(hipMemcpyAsync(m.rp, rp, (nrows + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPC(hipStreamSynchronize(ctx->stream));
+  m.present = true;
+  return ALFD_OK;
+}
+
+static int upload_transpose(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, const int64_t *rp,
+                            const int32_t *col, const double *val) {
+  const int64_t nnz = rp[nrows];
+  std::vector<int64_t> trp(ncols + 1, 0);
+  std::vector<int32_t> tcol(nnz);
+  std::vector<double> tval(nnz);
+  for (int64_t k = 0; k < nnz; ++k) trp[col[k] + 1]++;
+  for (int64_t r = 0; r < ncols; ++r) trp[r + 1] += trp[r];
+  std::vector<int64_t> cur(trp.begin(), trp.end() - 1);
+  for (int64_t r = 0; r < nrows; ++r)
+    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+      const int64_t p = cur[col[k]]++;
+      tcol[p] = (int32_t)r;
+      tval[p] = val[k];
+    }
+  return upload_matrix(ctx, slot, ncols, nrows, trp.data(), tcol.data(), tval.data());
+}
+
+static int nblocks_of(int variant) { return variant == ALFD_AL2 || variant == ALFD_RATIONAL ? 2 : 3; }
+
+static int setup(alfd_ctx *ctx) {
+  if (!ctx->configured) return ctx->err = "alfd_configure not called", ALFD_E_NOT_SETUP;
+  const alfd_config &c = ctx->cfg;
+  if (c.variant != ALFD_AL2 && c.variant != ALFD_AL_STOKES && c.variant != ALFD_AL_STOKES_DIAG)
+    return ctx->err = "variant not implemented yet", ALFD_E_UNSUPPORTED;
+  if (c.restart < 1 || c.restart > kMaxBasis - 1) return ctx->err = "restart out of range", ALFD_E_INVALID;
+  if (!c.grad_div_in_A && c.variant != ALFD_AL2)
+    return ctx->err = "grad_div_in_A = 0 (nested Bt Mp^-1 B in Aug) not implemented", ALFD_E_UNSUPPORTED;
+  ctx->nblocks = nblocks_of(c.variant);
+  const int last = ctx->nblocks - 1;
+  if (!ctx->mat[ALFD_A].present || !ctx->mat[ALFD_CT].present || !ctx->mat[ALFD_C].present ||
+      !ctx->diag[ALFD_INVW])
+    return ctx->err = "A, CT (and C) and INVW must be set", ALFD_E_NOT_SETUP;
+  ctx->n[0] = ctx->mat[ALFD_A].nrows;
+  ctx->n[last] = ctx->mat[ALFD_C].nrows;
+  if (ctx->nblocks == 3) {
+    if (!ctx->mat[ALFD_BT].present || !ctx->mat[ALFD_B].present || !ctx->mat[ALFD_MP].present ||
+        !ctx->diag[ALFD_MP_LUMPED_INV])
+      return ctx->err = "BT, B, MP and MP_LUMPED_INV must be set for the Stokes variants", ALFD_E_NOT_SETUP;
+    ctx->n[1] = ctx->mat[ALFD_B].nrows;
+  }
+  if (ctx->mat[ALFD_CT].nrows != ctx->n[0] || ctx->diag_n[ALFD_INVW] != ctx->n[last])
+    return ctx->err = "inconsistent block sizes", ALFD_E_INVALID;
+  ctx->nmax = 0;
+  for (int b = 0; b < ctx->nblocks; ++b) {
+    ctx->off[b + 1] = ctx->off[b] + pad_chunk(ctx->n[b]);
+    ctx->nmax = std::max(ctx->nmax, pad_chunk(ctx->n[b]));
+  }
+  const int64_t N = ctx->ntot(), n0p = pad_chunk(ctx->n[0]);
+  ctx->pstride = N / kChunk + 1;
+  RC(dev_alloc_zero(ctx, &ctx->sc, kNumScalars));
+  HIPC(hipHostMalloc((void **)&ctx->sc_host, kNumScalars * sizeof(double)));
+  RC(dev_alloc_zero(ctx, &ctx->partial, (int64_t)(kMaxBasis + 2) * ctx->pstride));
+  RC(dev_alloc_zero(ctx, &ctx->gather, (int64_t)ctx->nranks * (kMaxBasis + 2)));
+  RC(dev_alloc_zero(ctx, &ctx->dinv_aug, n0p));
+  RC(dev_alloc_zero(ctx, &ctx->dA, n0p));
+  RC(dev_alloc_zero(ctx, &ctx->s_aug, n0p));
+  RC(dev_alloc_zero(ctx, &ctx->w_r, ctx->nmax));
+  RC(dev_alloc_zero(ctx, &ctx->w_z, ctx->nmax));
+  RC(dev_alloc_zero(ctx, &ctx->w_p, ctx->nmax));
+  RC(dev_alloc_zero(ctx, &ctx->w_Ap, ctx->nmax));
+  RC(dev_alloc_zero(ctx, &ctx->c_d, n0p));
+  RC(dev_alloc_zero(ctx, &ctx->c_res, n0p));
+  RC(dev_alloc_zero(ctx, &ctx->c_tmp, n0p));
+  RC(dev_alloc_zero(ctx, &ctx->t_lam, pad_chunk(ctx->n[last])));
+  RC(dev_alloc_zero(ctx, &ctx->q_tmp, ctx->nmax));
+  RC(dev_alloc_zero(ctx, &ctx->rhs_tmp, n0p));
+  RC(dev_alloc_zero(ctx, &ctx->V, (int64_t)(c.restart + 1) * N));
+  RC(dev_alloc_zero(ctx, &ctx->Z, (int64_t)c.restart * N));
+  RC(dev_alloc_zero(ctx, &ctx->xb, N));
+  RC(dev_alloc_zero(ctx, &ctx->bb, N));
+  RC(dev_alloc_zero(ctx, &ctx->io, N));
+  // diag(Aug) = diag(A) + gamma * sum_k w_k Ct_ik^2
+  {
+    const DevCsr &A = ctx->mat[ALFD_A];
+    const DevCsr &Ct = ctx->mat[ALFD_CT];
+    const int grid = grid_for_rows(A.nrows, A.L);
+#define ALFD_DIAG(LL)                                                                                   \
+  hipLaunchKernelGGL((extract_diag_kernel<LL>), dim3(grid), dim3(kBlock), 0, ctx->stream, A.nrows, A.rp, \
+                     A.col, A.val, ctx->dA)
+    switch (A.L) {
+      case 4: ALFD_DIAG(4); break;
+      case 8: ALFD_DIAG(8); break;
+      case 16: ALFD_DIAG(16); break;
+      case 32: ALFD_DIAG(32); break;
+      default: ALFD_DIAG(64); break;
+    }
+#undef ALFD_DIAG
+    if (Ct.n_list > 0) {
+      if (ctx->nranks > 1 && (Ct.n_halo > 0 || Ct.send_off.back() > 0)) {
+        DevCsr &Ctm = ctx->mat[ALFD_CT];
+        RC(halo_exchange(ctx, Ctm, ctx->diag[ALFD_INVW]));
+      }
+      hipLaunchKernelGGL(aug_diag_rows_kernel, dim3((unsigned)((Ct.n_list + 255) / 256)), dim3(256), 0,
+                         ctx->stream, Ct.n_list, Ct.rp, Ct.col, Ct.val, Ct.sparse ? Ct.rows : nullptr,
+                         ctx->diag[ALFD_INVW], Ct.halo, Ct.n_local_cols, ctx->s_aug);
+    }
+    hipLaunchKernelGGL(aug_diag_finish_kernel, dim3((unsigned)((ctx->n[0] + 255) / 256)), dim3(256), 0,
+                       ctx->stream, ctx->n[0], c.gamma, ctx->dA, ctx->s_aug, ctx->dinv_aug);
+    HIPC(hipGetLastError());
+  }
+  ctx->lambda_max = ctx->lambda_min = 0;
+  if (c.inner_prec == ALFD_PREC_CHEBYSHEV) {
+    if (c.cheb_degree < 1 || c.cheb_power_its < 1 || !(c.cheb_eig_ratio > 1.0))
+      return ctx->err = "bad Chebyshev parameters", ALFD_E_INVALID;
+    double *v = ctx->w_p, *wv = ctx->w_Ap;
+    const int64_t goff = ctx->nranks > 1 ? ctx->part[0][ctx->rank] : 0;
+    hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((ctx->n[0] + 255) / 256)), dim3(256), 0,
+                       ctx->stream, ctx->n[0], goff, v);
+    double lam = 0;
+    for (int it = 0; it < c.cheb_power_its; ++it) {
+      RC(dot_async(ctx, n0p, v, v, S_TMP));
+      RC(read_scalars(ctx, S_TMP, 1));
+      const double nv = std::sqrt(ctx->sc_host[S_TMP]);
+      VEC_LAUNCH(scale_kernel, n0p, 16, (const double *)nullptr, 0, 0, 1.0 / nv, v);
+      RC(aug_apply(ctx, v, wv));
+      VEC_LAUNCH(pmul_scale_kernel, n0p, 24, 1.0, ctx->dinv_aug, wv, wv);
+      RC(dot_async(ctx, n0p, wv, wv, S_TMP));
+      RC(read_scalars(ctx, S_TMP, 1));
+      lam = std::sqrt(ctx->sc_host[S_TMP]);
+      std::swap(v, wv);
+    }
+    ctx->lambda_max = lam * c.cheb_safety;
+    ctx->lambda_min = ctx->lambda_max / c.cheb_eig_ratio;
+    HIPC(hipMemsetAsync(ctx->w_p, 0, ctx->nmax * sizeof(double), ctx->stream));
+    HIPC(hipMemsetAsync(ctx->w_Ap, 0, ctx->nmax * sizeof(double), ctx->stream));
+  }
+  HIPC(hipStreamSynchronize(ctx->stream));
+  ctx->is_setup = true;
+  return ALFD_OK;
+}
+
+// host blocks <-> padded device block vector
+static int to_device(alfd_ctx *ctx, const double *const *blocks, double *dev) {
+  HIPC(hipMemsetAsync(dev, 0, ctx->ntot() * sizeof(double), ctx->stream));
+  for (int b = 0; b < ctx->nblocks; ++b)
+    HIPC(hipMemcpyAsync(dev + ctx->off[b], blocks[b], ctx->n[b] * sizeof(double), hipMemcpyHostToDevice,
+                        ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  return ALFD_OK;
+}
+static int to_host(alfd_ctx *ctx, const double *dev, double *const *blocks) {
+  for (int b = 0; b < ctx->nblocks; ++b)
+    HIPC(hipMemcpyAsync(blocks[b], dev + ctx->off[b], ctx->n[b] * sizeof(double), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  return ALFD_OK;
+}
+
+static void reset_stats(alfd_ctx *ctx) {
+  ctx->inner_its = ctx->mp_its = 0;
+  ctx->inner_failures = ctx->precond_applications = 0;
+}
+static void fill_result(alfd_ctx *ctx, alfd_result *res, int status) {
+  res->status = status;
+  res->inner_iterations = ctx->inner_its;
+  res->mp_iterations = ctx->mp_its;
+  res->inner_failures = ctx->inner_failures;
+  res->precond_applications = ctx->precond_applications;
+  res->lambda_max = ctx->lambda_max;
+}
+
+}  // namespace alfd
+
+// =================================================================== C ABI
+#define CHECK_CTX()                       \
+  if (!ctx) return ALFD_E_INVALID;        \
+  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->err = "hipSetDevice failed", ALFD_E_HIP
+#define CHECK_SETUP() \
+  if (!ctx->is_setup) return ctx->err = "alfd_setup not called", ALFD_E_NOT_SETUP
+
+extern "C" {
+
+int alfd_abi_version(void) { return ALFD_ABI_VERSION; }
+
+const char *alfd_strerror(int s) {
+  switch (s) {
+    case ALFD_OK: return "ok";
+    case ALFD_E_INVALID: return "invalid argument";
+    case ALFD_E_HIP: return "HIP runtime error";
+    case ALFD_E_NO_CONVERGENCE_OUTER: return "FGMRES: no convergence (SolverControl::NoConvergence)";
+    case ALFD_E_NO_CONVERGENCE_INNER: return "inner CG: no convergence (SolverControl::NoConvergence)";
+    case ALFD_E_BREAKDOWN: return "breakdown (NaN residual)";
+    case ALFD_E_NOT_SETUP: return "context not set up";
+    case ALFD_E_COMM: return "RCCL error";
+    case ALFD_E_UNSUPPORTED: return "not implemented";
+    default: return "unknown status";
+  }
+}
+
+const char *alfd_last_error(alfd_ctx_t ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int alfd_create(alfd_ctx_t *out, int device_id) {
+  if (!out) return ALFD_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
+    return ALFD_E_HIP;  // no GPU: fail loudly, there is no CPU path
+  if (hipSetDevice(device_id) != hipSuccess) return ALFD_E_HIP;
+  alfd_ctx *ctx = new alfd_ctx;
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return ALFD_E_HIP;
+  }
+  alfd_default_config(&ctx->cfg, ALFD_AL_STOKES);
+  *out = ctx;
+  return ALFD_OK;
+}
+
+int alfd_destroy(alfd_ctx_t ctx) {
+  if (!ctx) return ALFD_E_INVALID;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  flush_timers(ctx);
+  for (void *p : ctx->allocs) hipFree(p);
+  if (ctx->sc_host) hipHostFree(ctx->sc_host);
+  if (ctx->nccl) ncclCommDestroy(ctx->nccl);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ALFD_OK;
+}
+
+int alfd_comm_unique_id(void *id_out, size_t bytes) {
+  static_assert(sizeof(ncclUniqueId) <= ALFD_UNIQUE_ID_BYTES, "unique id size");
+  if (!id_out || bytes < sizeof(ncclUniqueId)) return ALFD_E_INVALID;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return ALFD_E_COMM;
+  std::memset(id_out, 0, bytes);
+  std::memcpy(id_out, &id, sizeof(id));
+  return ALFD_OK;
+}
+
+int alfd_comm_init(alfd_ctx_t ctx, int rank, int nranks, const void *id, size_t bytes) {
+  CHECK_CTX();
+  if (nranks < 1 || rank < 0 || rank >= nranks) return ALFD_E_INVALID;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  if (nranks == 1) return ALFD_OK;
+  if (!id || bytes < sizeof(ncclUniqueId)) return ALFD_E_INVALID;
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  if (ncclCommInitRank(&ctx->nccl, nranks, uid, rank) != ncclSuccess)
+    return ctx->err = "ncclCommInitRank failed", ALFD_E_COMM;
+  return ALFD_OK;
+}
+
+int alfd_set_partition(alfd_ctx_t ctx, int nblocks, const int64_t *const *offsets) {
+  CHECK_CTX();
+  if (nblocks < 2 || nblocks > ALFD_MAX_BLOCKS || !offsets) return ALFD_E_INVALID;
+  ctx->part.assign(nblocks, {});
+  for (int b = 0; b < nblocks; ++b) {
+    ctx->part[b].assign(offsets[b], offsets[b] + ctx->nranks + 1);
+    for (int r = 0; r < ctx->nranks; ++r)
+      if (ctx->part[b][r + 1] < ctx->part[b][r]) return ctx->err = "partition not monotone", ALFD_E_INVALID;
+  }
+  ctx->nblocks = nblocks;
+  return ALFD_OK;
+}
+
+int alfd_set_matrix(alfd_ctx_t ctx, int slot, int64_t nrows, int64_t ncols, const int64_t *row_ptr,
+                    const int32_t *col, const double *val) {
+  CHECK_CTX();
+  if (slot < 0 || slot >= ALFD_NSLOTS || nrows < 0 || ncols < 0 || !row_ptr) return ALFD_E_INVALID;
+  if (ncols > 2147483647LL) return ctx->err = "more than 2^31-1 columns", ALFD_E_INVALID;
+  if (row_ptr[0] != 0) return ctx->err = "row_ptr[0] != 0", ALFD_E_INVALID;
+  const int64_t nnz = row_ptr[nrows];
+  if (nnz > 0 && (!col || !val)) return ALFD_E_INVALID;
+  for (int64_t r = 0; r < nrows; ++r)
+    if (row_ptr[r + 1] < row_ptr[r]) return ctx->err = "row_ptr not monotone", ALFD_E_INVALID;
+  for (int64_t k = 0; k < nnz; ++k)
+    if (col[k] < 0 || col[k] >= ncols) return ctx->err = "column index out of range", ALFD_E_INVALID;
+  ctx->is_setup = false;
+  if (ctx->nranks > 1 && ctx->nblocks == 0)
+    return ctx->err = "alfd_set_partition must precede alfd_set_matrix", ALFD_E_INVALID;
+  RC(upload_matrix(ctx, slot, nrows, ncols, row_ptr, col, val));
+  // single rank: the transposed operators are derived on upload, like
+  // transpose_operator(Ct) (stokes...:927); an explicit upload later overrides.
+  if (ctx->nranks == 1) {
+    if (slot == ALFD_CT && !ctx->mat[ALFD_C].present)
+      RC(upload_transpose(ctx, ALFD_C, nrows, ncols, row_ptr, col, val));
+    if (slot == ALFD_BT && !ctx->mat[ALFD_B].present)
+      RC(upload_transpose(ctx, ALFD_B, nrows, ncols, row_ptr, col, val));
+  }
+  return ALFD_OK;
+}
+
+int alfd_set_diag(alfd_ctx_t ctx, int slot, int64_t n, const double *d) {
+  CHECK_CTX();
+  if (slot < 0 || slot >= ALFD_NDIAGS || n < 0 || (n > 0 && !d)) return ALFD_E_INVALID;
+  ctx->is_setup = false;
+  RC(dev_alloc_zero(ctx, &ctx->diag[slot], pad_chunk(n)));
+  HIPC(hipMemcpyAsync(ctx->diag[slot], d, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  ctx->diag_n[slot] = n;
+  return ALFD_OK;
+}
+
+void alfd_default_config(alfd_config *c, int variant) {
+  std::memset(c, 0, sizeof(*c));
+  c->variant = variant;
+  c->restart = (variant == ALFD_AL_ELL_IDEAL || variant == ALFD_AL_ELL_MODIFIED) ? 50 : 30;
+  c->orthogonalization = ALFD_ORTH_CGS2;
+  c->grad_div_in_A = 1;
+  c->gamma = 10.0;
+  c->gamma_grad_div = 10.0;
+  c->gamma2 = 1e-2;
+  c->outer = {ALFD_CTRL_REDUCTION, 1000, 1e-8, 1e-12};
+  c->inner = {ALFD_CTRL_ABS, 100, 1e-2, 0.0};
+  c->mp_inner = {ALFD_CTRL_ABS, 100, 1e-6, 0.0};
+  c->inner_prec = ALFD_PREC_CHEBYSHEV;
+  c->cheb_degree = 4;
+  c->cheb_power_its = 20;
+  c->on_inner_failure = ALFD_INNER_THROW;
+  c->cheb_eig_ratio = 30.0;
+  c->cheb_safety = 1.2;
+  c->log_level = 0;
+}
+
+int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg) {
+  CHECK_CTX();
+  if (!cfg) return ALFD_E_INVALID;
+  if (cfg->variant < ALFD_AL2 || cfg->variant > ALFD_RATIONAL) return ALFD_E_INVALID;
+  ctx->cfg = *cfg;
+  ctx->configured = true;
+  ctx->is_setup = false;
+  return ALFD_OK;
+}
+
+int alfd_setup(alfd_ctx_t ctx) {
+  CHECK_CTX();
+  return setup(ctx);
+}
+
+int alfd_precond_apply(alfd_ctx_t ctx, const double *const *src, double *const *dst, alfd_result *res) {
+  CHECK_CTX();
+  CHECK_SETUP();
+  if (!src || !dst) return ALFD_E_INVALID;
+  reset_stats(ctx);
+  RC(to_device(ctx, src, ctx->bb));
+  HIPC(hipMemsetAsync(ctx->io, 0, ctx->ntot() * sizeof(double), ctx->stream));
+  const int rc = precond_apply(ctx, ctx->bb, ctx->io);
+  RC(to_host(ctx, ctx->io, dst));
+  if (res) {
+    std::memset(res, 0, sizeof(*res));
+    fill_result(ctx, res, rc);
+  }
+  return rc;
+}
+
+int alfd_system_apply(alfd_ctx_t ctx, const double *const *src, double *const *dst) {
+  CHECK_CTX();
+  CHECK_SETUP();
+  if (!src || !dst) return ALFD_E_INVALID;
+  RC(to_device(ctx, src, ctx->bb));
+  HIPC(hipMemsetAsync(ctx->io, 0, ctx->ntot() * sizeof(double), ctx->stream));
+  RC(system_apply(ctx, ctx->bb, ctx->io));
+  return to_host(ctx, ctx->io, dst);
+}
+
+int alfd_augment_rhs(alfd_ctx_t ctx, double *const *rhs) {
+  CHECK_CTX();
+  CHECK_SETUP();
+  if (!rhs) return ALFD_E_INVALID;
+  const int last = ctx->nblocks - 1;
+  RC(to_device(ctx, rhs, ctx->bb));
+  VEC_LAUNCH(pmul_scale_kernel, pad_chunk(ctx->n[last]), 24, 1.0, ctx->diag[ALFD_INVW],
+             ctx->bb + ctx->off[last], ctx->t_lam);
+  RC(spmv(ctx, ALFD_CT, ctx->t_lam, ctx->bb + ctx->off[0], 1, ctx->cfg.gamma));
+  return to_host(ctx, ctx->bb, rhs);
+}
+
+int alfd_upload_rhs(alfd_ctx_t ctx, const double *const *rhs, const double *const *x0) {
+  CHECK_CTX();
+  CHECK_SETUP();
+  if (!rhs) return ALFD_E_INVALID;
+  RC(to_device(ctx, rhs, ctx->bb));
+  if (x0)
+    RC(to_device(ctx, x0, ctx->io));
+  else
+    HIPC(hipMemsetAsync(ctx->io, 0, ctx->ntot() * sizeof(double), ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  return ALFD_OK;
+}
+
+int alfd_solve_resident(alfd_ctx_t ctx, alfd_result *res) {
+  CHECK_CTX();
+  CHECK_SETUP();
+  if (!res) return ALFD_E_INVALID;
+  std::memset(res, 0, sizeof(*res));
+  reset_stats(ctx);
+  // x <- initial guess kept in io (so the solve can be repeated)
+  HIPC(hipMemcpyAsync(ctx->xb, ctx->io, ctx->ntot() * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = fgmres(ctx, res);
+  hipStreamSynchronize(ctx->stream);
+  res->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  flush_timers(ctx);
+  fill_result(ctx, res, rc);
+  return rc;
+}
+
+int alfd_download_solution(alfd_ctx_t ctx, double *const *x) {
+  CHECK_CTX();
+  CHECK_SETUP();
+  if (!x) return ALFD_E_INVALID;
+  return to_host(ctx, ctx->xb, x);
+}
+
+int alfd_solve(alfd_ctx_t ctx, const double *const *rhs, double *const *x, alfd_result *res) {
+  CHECK_CTX();
+  CHECK_SETUP();
+  if (!rhs || !x || !res) return ALFD_E_INVALID;
+  RC(alfd_upload_rhs(ctx, rhs, x));
+  const int rc = alfd_solve_resident(ctx, res);
+  const int rc2 = alfd_download_solution(ctx, x);
+  return rc != ALFD_OK ? rc : rc2;
+}
+
+int alfd_get_history(alfd_ctx_t ctx, double *out, int32_t capacity, int32_t *count) {
+  if (!ctx) return ALFD_E_INVALID;
+  if (count) *count = (int32_t)ctx->history.size();
+  if (out)
+    for (int32_t i = 0; i < capacity && i < (int32_t)ctx->history.size(); ++i) out[i] = ctx->history[i];
+  return ALFD_OK;
+}
+
+int alfd_spmv(alfd_ctx_t ctx, int slot, const double *x, double *y, int mode, double alpha) {
+  CHECK_CTX();
+  if (slot < 0 || slot >= ALFD_NSLOTS || !ctx->mat[slot].present) return ALFD_E_INVALID;
+  if (!x || !y || (mode != 0 && mode != 1)) return ALFD_E_INVALID;
+  if (ctx->nranks > 1) return ctx->err = "alfd_spmv primitive is single-rank", ALFD_E_UNSUPPORTED;
+  const DevCsr &m = ctx->mat[slot];
+  double *dx = nullptr, *dy = nullptr;
+  HIPC(hipMalloc((void **)&dx, std::max<int64_t>(m.ncols, 1) * sizeof(double)));
+  HIPC(hipMalloc((void **)&dy, std::max<int64_t>(m.nrows, 1) * sizeof(double)));
+  HIPC(hipMemcpyAsync(dx, x, m.ncols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(dy, y, m.nrows * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const int rc = spmv(ctx, slot, dx, dy, mode, alpha);
+  if (rc == ALFD_OK) {
+    HIPC(hipMemcpyAsync(y, dy, m.nrows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+  }
+  hipFree(dx);
+  hipFree(dy);
+  return rc;
+}
+
+int alfd_dot(alfd_ctx_t ctx, int64_t n, const double *x, const double *y, double *result) {
+  CHECK_CTX();
+  if (n < 0 || !x || !y || !result) return ALFD_E_INVALID;
+  const int64_t npad = pad_chunk(std::max<int64_t>(n, 1));
+  double *dx = nullptr, *dy = nullptr, *part = nullptr, *sc = nullptr;
+  HIPC(hipMalloc((void **)&dx, npad * sizeof(double)));
+  HIPC(hipMalloc((void **)&dy, npad * sizeof(double)));
+  HIPC(hipMalloc((void **)&part, (npad / kChunk) * sizeof(double)));
+  HIPC(hipMalloc((void **)&sc, kNumScalars * sizeof(double)));
+  HIPC(hipMemsetAsync(dx, 0, npad * sizeof(double), ctx->stream));
+  HIPC(hipMemsetAsync(dy, 0, npad * sizeof(double), ctx->stream));
+  HIPC(hipMemcpyAsync(dx, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(dy, y, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)(npad / kChunk)), dim3(kBlock), 0, ctx->stream, dx,
+                     dy, part);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, part, npad / kChunk,
+                     (int64_t)0, sc, (int)S_TMP, (int)FIN_STORE);
+  HIPC(hipGetLastError());
+  HIPC(hipMemcpyAsync(result, sc + S_TMP, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  hipFree(dx);
+  hipFree(dy);
+  hipFree(part);
+  hipFree(sc);
+  return ALFD_OK;
+}
+
+int alfd_matrix_lanes(alfd_ctx_t ctx, int slot, int32_t *lanes) {
+  if (!ctx || slot < 0 || slot >= ALFD_NSLOTS || !lanes || !ctx->mat[slot].present) return ALFD_E_INVALID;
+  *lanes = ctx->mat[slot].L;
+  return ALFD_OK;
+}
+
+int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launch, double *bytes) {
+  CHECK_CTX();
+  if (slot < 0 || slot >= ALFD_NSLOTS || !ctx->mat[slot].present || reps < 1) return ALFD_E_INVALID;
+  if (ctx->nranks > 1) return ALFD_E_UNSUPPORTED;
+  const DevCsr &m = ctx->mat[slot];
+  double *dx = nullptr, *dy = nullptr;
+  HIPC(hipMalloc((void **)&dx, std::max<int64_t>(m.ncols, 1) * sizeof(double)));
+  HIPC(hipMalloc((void **)&dy, std::max<int64_t>(m.nrows, 1) * sizeof(double)));
+  hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, ctx->stream,
+                     m.ncols, (int64_t)0, dx);
+  const bool was = ctx->timing;
+  ctx->timing = false;
+  for (int i = 0; i < 2; ++i) RC(spmv(ctx, slot, dx, dy, 0));
+  hipEvent_t a, b;
+  HIPC(hipEventCreate(&a));
+  HIPC(hipEventCreate(&b));
+  HIPC(hipEventRecord(a, ctx->stream));
+  for (int i = 0; i < reps; ++i) RC(spmv(ctx, slot, dx, dy, 0));
+  HIPC(hipEventRecord(b, ctx->stream));
+  HIPC(hipEventSynchronize(b));
+  float ms = 0;
+  HIPC(hipEventElapsedTime(&ms, a, b));
+  ctx->timing = was;
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  hipFree(dx);
+  hipFree(dy);
+  if (ms_per_launch) *ms_per_launch = (double)ms / reps;
+  if (bytes) *bytes = m.algorithmic_bytes();
+  return ALFD_OK;
+}
+
+int alfd_enable_timing(alfd_ctx_t ctx, int on) {
+  if (!ctx) return ALFD_E_INVALID;
+  ctx->timing = on != 0;
+  for (int i = 0; i < ALFD_T_NCLASSES; ++i) ctx->t_ms[i] = 0, ctx->t_launches[i] = 0, ctx->t_bytes[i] = 0;
+  return ALFD_OK;
+}
+
+int alfd_get_timing(alfd_ctx_t ctx, double *ms, int64_t *launches, double *bytes) {
+  if (!ctx) return ALFD_E_INVALID;
+  flush_timers(ctx);
+  for (int i = 0; i < ALFD_T_NCLASSES; ++i) {
+    if (ms) ms[i] = ctx->t_ms[i];
+    if (launches) launches[i] = ctx->t_launches[i];
+    if (bytes) bytes[i] = ctx->t_bytes[i];
+  }
+  return ALFD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,458 @@
+// kernels.hpp -- hand-written HIP kernels for gfx950 (CDNA4, wave64).
+//
+// All kernels are HBM-bandwidth-bound fp64 sparse / streaming work (no MFMA by
+// design: SURVEY.md 8(d)).  Every reduction follows the fixed evaluation order
+// of "ALFD-arith v1"  so that results are bit-identical to
+// the CPU oracle:
+//   SpMV row : L lanes per row; lane l does fma over entries k0+l, k0+l+L, ..;
+//              xor-butterfly over the L lanes (lane 0 == binary tree).
+//   dot      : 4096-element chunk per 256-thread block; thread t takes the
+//              element pairs base + e*512 + 2t (e=0..7) with fma; 64-lane
+//              butterfly; (w0+w1)+(w2+w3); second stage = one block doing
+//              thread-strided adds and the same tree.
+// Replaces: dealii::SparseMatrix<double>::vmult /
+// vmult_add / Tvmult behind linear_operator() (stokes_immersed_boundary.cc:923-929)
+// and the Vector dot / add / sadd / equ primitives inside SolverCG / SolverFGMRES.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace alfd {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+constexpr int64_t kChunk = 4096;     // dot chunk == vector padding granule
+constexpr int kMaxBasis = 64;        // max FGMRES basis vectors handled by the batched kernels
+
+// --------------------------------------------------------------------------
+// wave / group reductions (xor butterfly; all lanes end with the tree value)
+template <int L>
+__device__ __forceinline__ double group_reduce(double v) {
+#pragma unroll
+  for (int s = L / 2; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+  return v;
+}
+
+// block of 256 threads -> (w0+w1)+(w2+w3), valid in thread 0
+__device__ __forceinline__ double block_reduce_256(double v, double *lds4) {
+  v = group_reduce<64>(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) lds4[wave] = v;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// --------------------------------------------------------------------------
+// CSR SpMV, L lanes per row, 256/L rows per workgroup, grid-stride over row
+// groups so that the resident workgroups sweep a compact moving window of rows
+// (x re-use out of L2 / Infinity Cache).
+//   EPI 0: y[r]  = s
+//   EPI 1: y[r]  = fma(alpha, s, y[r])          (vmult_add with a scalar)
+//   EPI 2: y[r]  = d[r] * s                      (diag-scaled: t = invW .* (C x))
+//   EPI 3: y[r]  = s and y2[r] = d[r] * s        (C x kept for the constraint row too)
+// SPARSE: rows[] lists the non-empty rows, rp[] is indexed by list position.
+// Columns >= n_local read the halo buffer (multi-GPU row partition).
+template <int L, int EPI, bool SPARSE>
+__global__ __launch_bounds__(kBlock) void spmv_kernel(int64_t nrows, const int64_t *__restrict__ rp,
+                                                      const int32_t *__restrict__ col,
+                                                      const double *__restrict__ val,
+                                                      const int32_t *__restrict__ rows,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ x_halo, int32_t n_local,
+                                                      double *__restrict__ y, double alpha,
+                                                      const double *__restrict__ d,
+                                                      double *__restrict__ y2) {
+  constexpr int RPB = kBlock / L;
+  const int lane = threadIdx.x % L;
+  const int sub = threadIdx.x / L;
+  const int64_t ngroups = (nrows + RPB - 1) / RPB;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t r = g * RPB + sub;
+    if (r < nrows) {  // uniform within the L-lane group
+      const int64_t k0 = rp[r], k1 = rp[r + 1];
+      double acc = 0.0;
+      for (int64_t k = k0 + lane; k < k1; k += L) {
+        const int32_t c = col[k];
+        const double xv = (c < n_local) ? x[c] : x_halo[c - n_local];
+        acc = fma(val[k], xv, acc);
+      }
+      acc = group_reduce<L>(acc);
+      if (lane == 0) {
+        const int64_t ro = SPARSE ? (int64_t)rows[r] : r;
+        if (EPI == 0)
+          y[ro] = acc;
+        else if (EPI == 1)
+          y[ro] = fma(alpha, acc, y[ro]);
+        else if (EPI == 2)
+          y[ro] = d[ro] * acc;
+        else {
+          y[ro] = acc;
+          y2[ro] = d[ro] * acc;
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// Streaming vector kernels. All vectors are padded to a multiple of kChunk with
+// zeros, so no bounds checks: one workgroup per chunk, thread t owns the pairs
+// base + e*512 + 2t -- the SAME mapping as the canonical dot, which lets the
+// fused "update + dot" kernels emit canonical partials.
+#define ALFD_FOR_PAIRS(i)                                   \
+  const int64_t base__ = (int64_t)blockIdx.x * kChunk;      \
+  _Pragma("unroll") for (int e__ = 0; e__ < 8; ++e__)       \
+      for (int64_t i = base__ + e__ * 512 + 2 * threadIdx.x, once__ = 1; once__; once__ = 0)
+
+__device__ __forceinline__ double2 ld2(const double *p, int64_t i) {
+  return *reinterpret_cast<const double2 *>(p + i);
+}
+__device__ __forceinline__ void st2(double *p, int64_t i, double2 v) {
+  *reinterpret_cast<double2 *>(p + i) = v;
+}
+
+// partial[b] = canonical chunk sum of x.y
+__global__ __launch_bounds__(kBlock) void dot_partial_kernel(const double *__restrict__ x,
+                                                             const double *__restrict__ y,
+                                                             double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  double acc = 0.0;
+  ALFD_FOR_PAIRS(i) {
+    const double2 a = ld2(x, i), b = ld2(y, i);
+    acc = fma(a.x, b.x, acc);
+    acc = fma(a.y, b.y, acc);
+  }
+  const double s = block_reduce_256(acc, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// Second stage for `count` dots at once: block j reduces partial[j*stride ..+nb).
+// post-ops on the device scalar table `sc` (so PCG needs no host round trip for
+// alpha / beta):
+//   FIN_STORE  : sc[out+j] = sum
+//   FIN_ALPHA  : sc[out] = sum (p.Ap); sc[S_ALPHA] = sc[S_RZ]/sum; sc[S_NALPHA] = -alpha
+//   FIN_RZ     : sc[S_RZ_OLD] = sc[S_RZ]; sc[S_RZ] = sum; sc[S_BETA] = sum / old
+enum { FIN_STORE = 0, FIN_ALPHA = 1, FIN_RZ = 2 };
+enum { S_RZ = 0, S_RZ_OLD = 1, S_PAP = 2, S_ALPHA = 3, S_NALPHA = 4, S_BETA = 5, S_RR = 6, S_TMP = 7, S_H = 8 };
+constexpr int S_STAGE = S_H + 2 * kMaxBasis;  // multi-rank local sums before the all-gather
+constexpr int kNumScalars = S_H + 3 * kMaxBasis + 8;
+
+__global__ __launch_bounds__(kBlock) void dot_final_kernel(const double *__restrict__ partial, int64_t nb,
+                                                           int64_t stride, double *__restrict__ sc,
+                                                           int out, int fin) {
+  __shared__ double lds4[4];
+  const double *p = partial + (int64_t)blockIdx.x * stride;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < nb; i += kBlock) acc = acc + p[i];
+  const double s = block_reduce_256(acc, lds4);
+  if (threadIdx.x == 0) {
+    if (fin == FIN_STORE) {
+      sc[out + blockIdx.x] = s;
+    } else if (fin == FIN_ALPHA) {
+      sc[S_PAP] = s;
+      const double a = sc[S_RZ] / s;
+      sc[S_ALPHA] = a;
+      sc[S_NALPHA] = -a;
+    } else {
+      const double old = sc[S_RZ];
+      sc[S_RZ_OLD] = old;
+      sc[S_RZ] = s;
+      sc[S_BETA] = s / old;
+    }
+  }
+}
+
+// Multi-rank second stage: sums nranks gathered local results in rank order.
+// in[r*count + j] -> sc[out + j]
+__global__ void rank_sum_kernel(const double *__restrict__ in, int nranks, int count,
+                                double *__restrict__ sc, int out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < count) {
+    double s = in[j];
+    for (int r = 1; r < nranks; ++r) s = s + in[(int64_t)r * count + j];
+    sc[out + j] = s;
+  }
+}
+
+// h_j partials for j < count: partial[j*stride + b] = chunk sum of V_j . w
+__global__ __launch_bounds__(kBlock) void multi_dot_partial_kernel(const double *__restrict__ V,
+                                                                   int64_t vstride, int count,
+                                                                   const double *__restrict__ w,
+                                                                   double *__restrict__ partial,
+                                                                   int64_t pstride) {
+  __shared__ double lds[kMaxBasis + 2][4];
+  double2 wr[8];
+  const int64_t base = (int64_t)blockIdx.x * kChunk;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) wr[e] = ld2(w, base + e * 512 + 2 * threadIdx.x);
+  const int wave = threadIdx.x >> 6;
+  for (int j = 0; j < count; ++j) {
+    const double *v = V + (int64_t)j * vstride;
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2 a = ld2(v, base + e * 512 + 2 * threadIdx.x);
+      acc = fma(a.x, wr[e].x, acc);
+      acc = fma(a.y, wr[e].y, acc);
+    }
+    acc = group_reduce<64>(acc);
+    if ((threadIdx.x & 63) == 0) lds[j][wave] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < count)
+    partial[(int64_t)threadIdx.x * pstride + blockIdx.x] =
+        (lds[threadIdx.x][0] + lds[threadIdx.x][1]) + (lds[threadIdx.x][2] + lds[threadIdx.x][3]);
+}
+
+// w = fma(-h_j, V_j, w) for j = 0..count-1 in order (h read from sc[hoff+j])
+__global__ __launch_bounds__(kBlock) void multi_axpy_neg_kernel(const double *__restrict__ V,
+                                                                int64_t vstride, int count,
+                                                                const double *__restrict__ sc, int hoff,
+                                                                double *__restrict__ w) {
+  ALFD_FOR_PAIRS(i) {
+    double2 a = ld2(w, i);
+    for (int j = 0; j < count; ++j) {
+      const double h = -sc[hoff + j];
+      const double2 v = ld2(V + (int64_t)j * vstride, i);
+      a.x = fma(h, v.x, a.x);
+      a.y = fma(h, v.y, a.y);
+    }
+    st2(w, i, a);
+  }
+}
+
+// x = fma(y_j, Z_j, x) for j in order, y on the host side -> passed via sc[hoff+j]
+__global__ __launch_bounds__(kBlock) void multi_axpy_kernel(const double *__restrict__ Z, int64_t zstride,
+                                                            int count, const double *__restrict__ sc,
+                                                            int hoff, double *__restrict__ x) {
+  ALFD_FOR_PAIRS(i) {
+    double2 a = ld2(x, i);
+    for (int j = 0; j < count; ++j) {
+      const double h = sc[hoff + j];
+      const double2 v = ld2(Z + (int64_t)j * zstride, i);
+      a.x = fma(h, v.x, a.x);
+      a.y = fma(h, v.y, a.y);
+    }
+    st2(x, i, a);
+  }
+}
+
+// y = fma(a, x, y); a = sc[ai] when sc != nullptr else aval
+__global__ __launch_bounds__(kBlock) void axpy_kernel(const double *__restrict__ sc, int ai, double aval,
+                                                      const double *__restrict__ x, double *__restrict__ y) {
+  const double a = sc ? sc[ai] : aval;
+  ALFD_FOR_PAIRS(i) {
+    const double2 xv = ld2(x, i);
+    double2 yv = ld2(y, i);
+    yv.x = fma(a, xv.x, yv.x);
+    yv.y = fma(a, xv.y, yv.y);
+    st2(y, i, yv);
+  }
+}
+
+// x *= a  (a = 1/sc[ai] when inv, for the Arnoldi normalisation v /= ||v||)
+__global__ __launch_bounds__(kBlock) void scale_kernel(const double *__restrict__ sc, int ai, int inv_sqrt,
+                                                       double aval, double *__restrict__ x) {
+  double a = aval;
+  if (sc) a = inv_sqrt ? 1.0 / sqrt(sc[ai]) : sc[ai];
+  ALFD_FOR_PAIRS(i) {
+    double2 v = ld2(x, i);
+    v.x = a * v.x;
+    v.y = a * v.y;
+    st2(x, i, v);
+  }
+}
+
+// y = a * x
+__global__ __launch_bounds__(kBlock) void scale_copy_kernel(double a, const double *__restrict__ x,
+                                                            double *__restrict__ y) {
+  ALFD_FOR_PAIRS(i) {
+    double2 v = ld2(x, i);
+    v.x = a * v.x;
+    v.y = a * v.y;
+    st2(y, i, v);
+  }
+}
+
+// v = b - v
+__global__ __launch_bounds__(kBlock) void sub_from_kernel(const double *__restrict__ b,
+                                                          double *__restrict__ v) {
+  ALFD_FOR_PAIRS(i) {
+    const double2 bv = ld2(b, i);
+    double2 vv = ld2(v, i);
+    vv.x = bv.x - vv.x;
+    vv.y = bv.y - vv.y;
+    st2(v, i, vv);
+  }
+}
+
+// y = a * (d .* x)          (v2 = -gamma invW u2, ...preconditioner.h:32,66)
+__global__ __launch_bounds__(kBlock) void pmul_scale_kernel(double a, const double *__restrict__ d,
+                                                            const double *__restrict__ x,
+                                                            double *__restrict__ y) {
+  ALFD_FOR_PAIRS(i) {
+    const double2 dv = ld2(d, i), xv = ld2(x, i);
+    double2 yv;
+    yv.x = a * (dv.x * xv.x);
+    yv.y = a * (dv.y * xv.y);
+    st2(y, i, yv);
+  }
+}
+
+// ---- PCG fused kernels (canonical dot partials come out of the same pass)
+// z = d .* r ; partial = chunk sum of r.z            (Jacobi + r.z)
+__global__ __launch_bounds__(kBlock) void jacobi_dot_kernel(const double *__restrict__ d,
+                                                            const double *__restrict__ r,
+                                                            double *__restrict__ z,
+                                                            double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  double acc = 0.0;
+  ALFD_FOR_PAIRS(i) {
+    const double2 dv = ld2(d, i), rv = ld2(r, i);
+    double2 zv;
+    zv.x = dv.x * rv.x;
+    zv.y = dv.y * rv.y;
+    st2(z, i, zv);
+    acc = fma(rv.x, zv.x, acc);
+    acc = fma(rv.y, zv.y, acc);
+  }
+  const double s = block_reduce_256(acc, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// p = fma(beta, p, z)  (first: p = z)
+__global__ __launch_bounds__(kBlock) void p_update_kernel(const double *__restrict__ sc, int first,
+                                                          const double *__restrict__ z,
+                                                          double *__restrict__ p) {
+  const double beta = first ? 0.0 : sc[S_BETA];
+  ALFD_FOR_PAIRS(i) {
+    const double2 zv = ld2(z, i);
+    if (first) {
+      st2(p, i, zv);
+    } else {
+      double2 pv = ld2(p, i);
+      pv.x = fma(beta, pv.x, zv.x);
+      pv.y = fma(beta, pv.y, zv.y);
+      st2(p, i, pv);
+    }
+  }
+}
+
+// x = fma(alpha, p, x); r = fma(-alpha, Ap, r); partial = chunk sum of r.r
+__global__ __launch_bounds__(kBlock) void xr_update_dot_kernel(const double *__restrict__ sc,
+                                                               const double *__restrict__ p,
+                                                               const double *__restrict__ Ap,
+                                                               double *__restrict__ x,
+                                                               double *__restrict__ r,
+                                                               double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  const double a = sc[S_ALPHA], na = sc[S_NALPHA];
+  double acc = 0.0;
+  ALFD_FOR_PAIRS(i) {
+    const double2 pv = ld2(p, i), av = ld2(Ap, i);
+    double2 xv = ld2(x, i), rv = ld2(r, i);
+    xv.x = fma(a, pv.x, xv.x);
+    xv.y = fma(a, pv.y, xv.y);
+    rv.x = fma(na, av.x, rv.x);
+    rv.y = fma(na, av.y, rv.y);
+    st2(x, i, xv);
+    st2(r, i, rv);
+    acc = fma(rv.x, rv.x, acc);
+    acc = fma(rv.y, rv.y, acc);
+  }
+  const double s = block_reduce_256(acc, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// ---- Chebyshev (Saad Alg. 12.1, zero start) on D^-1 Aug
+// d = inv_theta * (dinv .* r); z = d; res = r
+__global__ __launch_bounds__(kBlock) void cheb_init_kernel(double inv_theta, const double *__restrict__ dinv,
+                                                           const double *__restrict__ r,
+                                                           double *__restrict__ d, double *__restrict__ z,
+                                                           double *__restrict__ res, int keep_res) {
+  ALFD_FOR_PAIRS(i) {
+    const double2 dv = ld2(dinv, i), rv = ld2(r, i);
+    double2 o;
+    o.x = inv_theta * (dv.x * rv.x);
+    o.y = inv_theta * (dv.y * rv.y);
+    st2(d, i, o);
+    st2(z, i, o);
+    if (keep_res) st2(res, i, rv);
+  }
+}
+// res -= tmp; d = fma(c1, d, c2 * (dinv .* res)); z += d
+__global__ __launch_bounds__(kBlock) void cheb_step_kernel(double c1, double c2,
+                                                           const double *__restrict__ dinv,
+                                                           const double *__restrict__ tmp,
+                                                           double *__restrict__ res, double *__restrict__ d,
+                                                           double *__restrict__ z) {
+  ALFD_FOR_PAIRS(i) {
+    const double2 dv = ld2(dinv, i), tv = ld2(tmp, i);
+    double2 rv = ld2(res, i), dd = ld2(d, i), zv = ld2(z, i);
+    rv.x = rv.x - tv.x;
+    rv.y = rv.y - tv.y;
+    dd.x = fma(c1, dd.x, c2 * (dv.x * rv.x));
+    dd.y = fma(c1, dd.y, c2 * (dv.y * rv.y));
+    zv.x = zv.x + dd.x;
+    zv.y = zv.y + dd.y;
+    st2(res, i, rv);
+    st2(d, i, dd);
+    st2(z, i, zv);
+  }
+}
+
+// ---- setup kernels
+// dA[r] = A_rr (exact copy, no arithmetic); diag column = r + row_offset, and
+// locally that is column (r) when the matrix's local columns come first.
+template <int L>
+__global__ __launch_bounds__(kBlock) void extract_diag_kernel(int64_t nrows, const int64_t *__restrict__ rp,
+                                                              const int32_t *__restrict__ col,
+                                                              const double *__restrict__ val,
+                                                              double *__restrict__ dA) {
+  constexpr int RPB = kBlock / L;
+  const int lane = threadIdx.x % L, sub = threadIdx.x / L;
+  const int64_t ngroups = (nrows + RPB - 1) / RPB;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t r = g * RPB + sub;
+    if (r < nrows)
+      for (int64_t k = rp[r] + lane; k < rp[r + 1]; k += L)
+        if (col[k] == (int32_t)r) dA[r] = val[k];
+  }
+}
+// dinv[i] = 1 / fma(gamma, s_i, dA[i]), s_i = sequential fma over row i of Ct of
+// (w[c] * v) * v ; one thread per non-empty row of Ct; other rows: 1/dA.
+__global__ void aug_diag_rows_kernel(int64_t n_sr, const int64_t *__restrict__ rp,
+                                     const int32_t *__restrict__ col, const double *__restrict__ val,
+                                     const int32_t *__restrict__ rows, const double *__restrict__ w,
+                                     const double *__restrict__ w_halo, int32_t n_local,
+                                     double *__restrict__ s_out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_sr) {
+    double s = 0.0;
+    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+      const int32_t c = col[k];
+      const double wv = c < n_local ? w[c] : w_halo[c - n_local];
+      s = fma(wv * val[k], val[k], s);
+    }
+    s_out[rows ? rows[r] : r] = s;
+  }
+}
+__global__ void aug_diag_finish_kernel(int64_t n, double gamma, const double *__restrict__ dA,
+                                       const double *__restrict__ s, double *__restrict__ dinv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dinv[i] = 1.0 / fma(gamma, s[i], dA[i]);
+}
+// power-iteration start vector: v_i = 1 + ((g*2654435761) & 1023)/1024, g = global index
+__global__ void hash_vector_kernel(int64_t n, int64_t goff, double *__restrict__ v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    v[i] = 1.0 + (double)(((uint64_t)(i + goff) * 2654435761ull) & 1023ull) * (1.0 / 1024.0);
+}
+
+// gather x[idx[i]] -> out[i]   (halo send packing)
+__global__ void gather_kernel(int64_t n, const int32_t *__restrict__ idx, const double *__restrict__ x,
+                              double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[idx[i]];
+}
+
+}  // namespace alfd

@@ -1,0 +1,214 @@
+"""Synthetic fictitious-domain problems (inputs of the hot path).
+
+Thin ctypes front-end of ``csrc/synth/synth.cpp``.  The reference gets these
+operators from deal.II FE assembly (immersed_laplace.cc:278-496,
+stokes_immersed_boundary.cc:410-820); deal.II is not available, so the
+generator builds structurally faithful CSR blocks on tensor grids -- the
+concrete instances are the rows of SURVEY.md section 8(d).
+
+Nothing here does solver arithmetic; it only produces host CSR arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libalfd_synth.so")
+_lib = None
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("degree", C.c_int32), ("ncomp", C.c_int32), ("n_cells", C.c_int32),
+        ("lo", C.c_double), ("hi", C.c_double),
+        ("stokes", C.c_int32), ("grad_div", C.c_int32),
+        ("gamma_grad_div", C.c_double), ("beta", C.c_double),
+        ("center", C.c_double * 3), ("radius", C.c_double),
+        ("immersed_refine", C.c_int32), ("coupling_nq", C.c_int32),
+        ("body_force", C.c_double * 3), ("embedded_value", C.c_double * 3),
+    ]
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(_LIB_PATH)
+        lib.alfd_synth_generate.restype = C.c_void_p
+        lib.alfd_synth_generate.argtypes = [C.POINTER(_Params), C.c_char_p, C.c_int]
+        lib.alfd_synth_free.argtypes = [C.c_void_p]
+        lib.alfd_synth_matrix.restype = C.c_int
+        lib.alfd_synth_matrix.argtypes = [
+            C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+            C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int32)),
+            C.POINTER(C.POINTER(C.c_double))]
+        lib.alfd_synth_vector.restype = C.c_int
+        lib.alfd_synth_vector.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64),
+                                          C.POINTER(C.POINTER(C.c_double))]
+        lib.alfd_synth_transpose.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+@dataclass
+class Csr:
+    """Host CSR block: int64 row_ptr, int32 col (ascending per row), fp64 val."""
+    nrows: int
+    ncols: int
+    row_ptr: np.ndarray
+    col: np.ndarray
+    val: np.ndarray
+
+    @property
+    def nnz(self) -> int:
+        return int(self.row_ptr[-1])
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.val, self.col, self.row_ptr), shape=(self.nrows, self.ncols))
+
+    @staticmethod
+    def from_scipy(m) -> "Csr":
+        m = m.tocsr()
+        m.sort_indices()
+        return Csr(m.shape[0], m.shape[1], m.indptr.astype(np.int64), m.indices.astype(np.int32),
+                   m.data.astype(np.float64))
+
+    def transpose(self) -> "Csr":
+        lib = _load()
+        rp = np.empty(self.ncols + 1, np.int64)
+        col = np.empty(self.nnz, np.int32)
+        val = np.empty(self.nnz, np.float64)
+        lib.alfd_synth_transpose(self.nrows, self.ncols, self.row_ptr.ctypes.data, self.col.ctypes.data,
+                                 self.val.ctypes.data, rp.ctypes.data, col.ctypes.data, val.ctypes.data)
+        return Csr(self.ncols, self.nrows, rp, col, val)
+
+    def diagonal(self) -> np.ndarray:
+        d = np.zeros(self.nrows)
+        rows = np.repeat(np.arange(self.nrows, dtype=np.int64), np.diff(self.row_ptr))
+        mask = rows == self.col
+        d[rows[mask]] = self.val[mask]
+        return d
+
+
+@dataclass
+class SyntheticProblem:
+    """CSR blocks + right-hand sides of one fictitious-domain system.
+
+    mats: "A" (n_u x n_u), "Ct" (n_u x n_l), "C", "M", "K" (immersed mass /
+    stiffness), and for Stokes "B", "Bt", "Mp".  vecs: "f", "g" (and "rhs_p").
+    """
+    params: dict
+    mats: dict = field(default_factory=dict)
+    vecs: dict = field(default_factory=dict)
+    _handle: object = None
+
+    @property
+    def block_sizes(self):
+        n_u = self.mats["A"].nrows
+        n_l = self.mats["Ct"].ncols
+        if "B" in self.mats:
+            return [n_u, self.mats["B"].nrows, n_l]
+        return [n_u, n_l]
+
+    def inv_w_diag_squared(self) -> np.ndarray:
+        """W^-1 = 1 / M_ii^2 (stokes_immersed_boundary.cc:976-978, immersed_laplace.cc:866-869)."""
+        d = self.mats["M"].diagonal()
+        return 1.0 / (d * d)
+
+    def mp_lumped_inv(self) -> np.ndarray:
+        """1 / (Mp 1)_i  (stokes_immersed_boundary.cc:946-954)."""
+        mp = self.mats["Mp"]
+        s = np.add.reduceat(mp.val, mp.row_ptr[:-1])
+        return 1.0 / s
+
+    def __del__(self):
+        if self._handle is not None and _lib is not None:
+            _lib.alfd_synth_free(self._handle)
+            self._handle = None
+
+
+def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False, grad_div=False,
+             gamma_grad_div=0.0, beta=1.0, center=(0.5, 0.5, 0.5), radius=0.2, immersed_refine=3,
+             coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0)) -> SyntheticProblem:
+    lib = _load()
+    p = _Params()
+    p.dim, p.degree, p.ncomp, p.n_cells = dim, degree, ncomp, n_cells
+    p.lo, p.hi = lo, hi
+    p.stokes, p.grad_div = int(stokes), int(grad_div)
+    p.gamma_grad_div, p.beta = gamma_grad_div, beta
+    for i in range(3):
+        p.center[i] = center[i] if i < len(center) else 0.0
+        p.body_force[i] = body_force[i] if i < len(body_force) else 0.0
+        p.embedded_value[i] = embedded_value[i] if i < len(embedded_value) else 0.0
+    p.radius, p.immersed_refine, p.coupling_nq = radius, immersed_refine, coupling_nq
+    err = C.create_string_buffer(256)
+    h = lib.alfd_synth_generate(C.byref(p), err, 256)
+    if not h:
+        raise ValueError("synthetic generator: " + err.value.decode())
+    params = dict(dim=dim, degree=degree, ncomp=ncomp, n_cells=n_cells, lo=lo, hi=hi, stokes=stokes,
+                  grad_div=grad_div, gamma_grad_div=gamma_grad_div, beta=beta, center=tuple(center),
+                  radius=radius, immersed_refine=immersed_refine, coupling_nq=coupling_nq)
+    pb = SyntheticProblem(params=params, _handle=C.c_void_p(h))
+    for name in ("A", "B", "Bt", "Mp", "Ct", "C", "M", "K"):
+        nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        rp, col, val = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
+        if lib.alfd_synth_matrix(pb._handle, name.encode(), C.byref(nr), C.byref(nc), C.byref(nnz),
+                                 C.byref(rp), C.byref(col), C.byref(val)) != 0:
+            continue
+        n = max(nnz.value, 1)
+        pb.mats[name] = Csr(
+            nr.value, nc.value,
+            np.ctypeslib.as_array(rp, shape=(nr.value + 1,)),
+            np.ctypeslib.as_array(col, shape=(n,))[:nnz.value],
+            np.ctypeslib.as_array(val, shape=(n,))[:nnz.value])
+    for name in ("f", "g", "rhs_p", "immersed_xyz"):
+        n, data = C.c_int64(), C.POINTER(C.c_double)()
+        if lib.alfd_synth_vector(pb._handle, name.encode(), C.byref(n), C.byref(data)) != 0:
+            continue
+        pb.vecs[name] = np.ctypeslib.as_array(data, shape=(max(n.value, 1),))[:n.value]
+    return pb
+
+
+# ---------------------------------------------------------------------------
+# The BASELINE.json configs as concrete synthetic instances.
+def laplace2d_circle(n_cells=64, immersed_refine=5, coupling_nq=3) -> SyntheticProblem:
+    """cfg 1: immersed_laplace 2-D, parameters/circle/Circle_parameters_f0_g1.prm
+    (f = 0, g = 1, R = 0.2, centre (0.4, 0.4)), Q1 background on [0,1]^2."""
+    return generate(dim=2, degree=1, ncomp=1, n_cells=n_cells, center=(0.4, 0.4, 0.0), radius=0.2,
+                    immersed_refine=immersed_refine, coupling_nq=coupling_nq,
+                    body_force=(0.0,), embedded_value=(1.0,))
+
+
+def laplace3d_sphere(n_cells=128, immersed_refine=5, coupling_nq=3) -> SyntheticProblem:
+    """cfg 2: immersed_laplace 3-D, Q1 on n^3 cells, cubed-sphere surface R = 0.2."""
+    return generate(dim=3, degree=1, ncomp=1, n_cells=n_cells, center=(0.5, 0.5, 0.5), radius=0.2,
+                    immersed_refine=immersed_refine, coupling_nq=coupling_nq,
+                    body_force=(0.0,), embedded_value=(1.0,))
+
+
+def stokes3d_sphere(n_cells=64, immersed_refine=4, gamma_grad_div=10.0, coupling_nq=4) -> SyntheticProblem:
+    """cfg 4 (north star): stokes_immersed_boundary + parameters_stokes_3d.prm.
+    Taylor-Hood Q2/Q1 on n^3 cells, grad-div on (prm:21), sphere R = 0.1 centre
+    (.5,.5,.5) (stokes_immersed_boundary.cc:427), body force (1,0,0) (prm:52),
+    embedded value (-1,1,0) (prm:134)."""
+    return generate(dim=3, degree=2, ncomp=3, n_cells=n_cells, stokes=True, grad_div=True,
+                    gamma_grad_div=gamma_grad_div, center=(0.5, 0.5, 0.5), radius=0.1,
+                    immersed_refine=immersed_refine, coupling_nq=coupling_nq,
+                    body_force=(1.0, 0.0, 0.0), embedded_value=(-1.0, 1.0, 0.0))
+
+
+def stokes2d_circle(n_cells=32, immersed_refine=4, gamma_grad_div=10.0, coupling_nq=3) -> SyntheticProblem:
+    """2-D Taylor-Hood + immersed circle (what the reference binary is compiled
+    for: stokes_immersed_boundary.cc:1218-1219, parameters_stokes.prm)."""
+    return generate(dim=2, degree=2, ncomp=2, n_cells=n_cells, stokes=True, grad_div=True,
+                    gamma_grad_div=gamma_grad_div, center=(0.5, 0.5, 0.0), radius=0.2,
+                    immersed_refine=immersed_refine, coupling_nq=coupling_nq,
+                    body_force=(1.0, 0.0), embedded_value=(-1.0, 1.0))

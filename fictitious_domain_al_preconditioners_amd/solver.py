@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference's solver interface over the C ABI.
+
+Everything here goes through ``lib/libalfd.so`` (include/alfd/alfd.h); there is
+no Python or CPU fallback: if the HIP library is missing or no GPU is present
+the calls raise.  The class names and ``vmult(dst, src)`` / ``solve(A, x, b, P)``
+signatures follow the reference (augmented_lagrangian_preconditioner.h:14-110,
+stokes_immersed_boundary.cc:1067-1074) so that tests read like the call sites.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libalfd.so")
+_lib = None
+
+# every symbol include/alfd/alfd.h declares
+ABI_SYMBOLS = [
+    "alfd_abi_version", "alfd_strerror", "alfd_last_error", "alfd_create", "alfd_destroy",
+    "alfd_comm_unique_id", "alfd_comm_init", "alfd_set_partition", "alfd_set_matrix", "alfd_set_diag",
+    "alfd_configure", "alfd_default_config", "alfd_setup", "alfd_precond_apply", "alfd_system_apply",
+    "alfd_augment_rhs", "alfd_solve", "alfd_upload_rhs", "alfd_solve_resident", "alfd_download_solution",
+    "alfd_get_history", "alfd_spmv", "alfd_dot", "alfd_matrix_lanes", "alfd_bench_spmv",
+    "alfd_enable_timing", "alfd_get_timing",
+]
+
+
+class AlfdError(RuntimeError):
+    """Non-zero status from the C ABI.  NoConvergence mirrors
+    dealii::SolverControl::NoConvergence (stokes_immersed_boundary.cc:1233-1254)."""
+
+    def __init__(self, status, message):
+        super().__init__(f"alfd status {status}: {message}")
+        self.status = status
+
+
+class NoConvergence(AlfdError):
+    pass
+
+
+def load_library():
+    """dlopen libalfd.so; raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
+                          "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    PP = C.POINTER(C.c_void_p)
+    sig = {
+        "alfd_abi_version": (C.c_int, []),
+        "alfd_strerror": (C.c_char_p, [C.c_int]),
+        "alfd_last_error": (C.c_char_p, [vp]),
+        "alfd_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "alfd_destroy": (C.c_int, [vp]),
+        "alfd_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
+        "alfd_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t]),
+        "alfd_set_partition": (C.c_int, [vp, C.c_int, PP]),
+        "alfd_set_matrix": (C.c_int, [vp, C.c_int, i64, i64, vp, vp, vp]),
+        "alfd_set_diag": (C.c_int, [vp, C.c_int, i64, vp]),
+        "alfd_configure": (C.c_int, [vp, C.POINTER(_abi.Config)]),
+        "alfd_default_config": (None, [C.POINTER(_abi.Config), C.c_int]),
+        "alfd_setup": (C.c_int, [vp]),
+        "alfd_precond_apply": (C.c_int, [vp, PP, PP, C.POINTER(_abi.Result)]),
+        "alfd_system_apply": (C.c_int, [vp, PP, PP]),
+        "alfd_augment_rhs": (C.c_int, [vp, PP]),
+        "alfd_solve": (C.c_int, [vp, PP, PP, C.POINTER(_abi.Result)]),
+        "alfd_upload_rhs": (C.c_int, [vp, PP, PP]),
+        "alfd_solve_resident": (C.c_int, [vp, C.POINTER(_abi.Result)]),
+        "alfd_download_solution": (C.c_int, [vp, PP]),
+        "alfd_get_history": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
+        "alfd_spmv": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, dbl]),
+        "alfd_dot": (C.c_int, [vp, i64, vp, vp, C.POINTER(dbl)]),
+        "alfd_matrix_lanes": (C.c_int, [vp, C.c_int, C.POINTER(i32)]),
+        "alfd_bench_spmv": (C.c_int, [vp, C.c_int, i32, C.POINTER(dbl), C.POINTER(dbl)]),
+        "alfd_enable_timing": (C.c_int, [vp, C.c_int]),
+        "alfd_get_timing": (C.c_int, [vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _blocks(arrs):
+    a = (C.c_void_p * len(arrs))()
+    for i, x in enumerate(arrs):
+        a[i] = x.ctypes.data
+    return a
+
+
+class Context:
+    """One alfd_ctx_t: one GPU, HBM-resident operators."""
+
+    def __init__(self, device_id=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.alfd_create(C.byref(self._h), device_id)
+        if rc != _abi.OK:
+            self._h = None
+            raise AlfdError(rc, "alfd_create failed: " + self._lib.alfd_strerror(rc).decode() +
+                            " (a HIP device is required; there is no CPU path)")
+        self.block_sizes = None
+        self.cfg = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.alfd_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc != _abi.OK:
+            msg = self._lib.alfd_last_error(self._h).decode() or self._lib.alfd_strerror(rc).decode()
+            cls = NoConvergence if rc in (_abi.E_NO_CONVERGENCE_OUTER, _abi.E_NO_CONVERGENCE_INNER) else AlfdError
+            raise cls(rc, msg)
+
+    # -- multi-GPU
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(_abi.UNIQUE_ID_BYTES)
+        rc = load_library().alfd_comm_unique_id(buf, _abi.UNIQUE_ID_BYTES)
+        if rc != _abi.OK:
+            raise AlfdError(rc, "alfd_comm_unique_id failed")
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id: bytes):
+        self._ck(self._lib.alfd_comm_init(self._h, rank, nranks, unique_id, len(unique_id)))
+
+    def set_partition(self, offsets):
+        arrs = [np.ascontiguousarray(o, np.int64) for o in offsets]
+        self._ck(self._lib.alfd_set_partition(self._h, len(arrs), _blocks(arrs)))
+
+    # -- upload
+    def set_matrix(self, slot, m):
+        rp = np.ascontiguousarray(m.row_ptr, np.int64)
+        col = np.ascontiguousarray(m.col, np.int32)
+        val = np.ascontiguousarray(m.val, np.float64)
+        self._ck(self._lib.alfd_set_matrix(self._h, slot, m.nrows, m.ncols, rp.ctypes.data, col.ctypes.data,
+                                           val.ctypes.data))
+
+    def set_diag(self, slot, d):
+        d = np.ascontiguousarray(d, np.float64)
+        self._ck(self._lib.alfd_set_diag(self._h, slot, d.size, d.ctypes.data))
+
+    def configure(self, cfg: _abi.Config):
+        self.cfg = cfg
+        self._ck(self._lib.alfd_configure(self._h, C.byref(cfg)))
+
+    def setup(self, block_sizes):
+        self._ck(self._lib.alfd_setup(self._h))
+        self.block_sizes = [int(b) for b in block_sizes]
+
+    # -- hot path
+    def _in(self, blocks):
+        out = [np.ascontiguousarray(b, np.float64) for b in blocks]
+        if [b.size for b in out] != self.block_sizes:
+            raise ValueError(f"block sizes {[b.size for b in out]} != {self.block_sizes}")
+        return out
+
+    def precond_apply(self, src):
+        src = self._in(src)
+        dst = [np.zeros(n) for n in self.block_sizes]
+        res = _abi.Result()
+        self._ck(self._lib.alfd_precond_apply(self._h, _blocks(src), _blocks(dst), C.byref(res)))
+        return dst, res
+
+    def system_apply(self, src):
+        src = self._in(src)
+        dst = [np.zeros(n) for n in self.block_sizes]
+        self._ck(self._lib.alfd_system_apply(self._h, _blocks(src), _blocks(dst)))
+        return dst
+
+    def augment_rhs(self, rhs):
+        rhs = [b.copy() for b in self._in(rhs)]
+        self._ck(self._lib.alfd_augment_rhs(self._h, _blocks(rhs)))
+        return rhs
+
+    def solve(self, rhs, x0=None, raise_on_failure=True):
+        rhs = self._in(rhs)
+        x = [np.zeros(n) for n in self.block_sizes] if x0 is None else [b.copy() for b in self._in(x0)]
+        res = _abi.Result()
+        rc = self._lib.alfd_solve(self._h, _blocks(rhs), _blocks(x), C.byref(res))
+        if rc != _abi.OK and raise_on_failure:
+            self._ck(rc)
+        return x, res
+
+    def upload_rhs(self, rhs, x0=None):
+        rhs = self._in(rhs)
+        x0b = _blocks(self._in(x0)) if x0 is not None else None
+        self._ck(self._lib.alfd_upload_rhs(self._h, _blocks(rhs), x0b))
+
+    def solve_resident(self, raise_on_failure=True):
+        res = _abi.Result()
+        rc = self._lib.alfd_solve_resident(self._h, C.byref(res))
+        if rc != _abi.OK and raise_on_failure:
+            self._ck(rc)
+        return res
+
+    def download_solution(self):
+        x = [np.zeros(n) for n in self.block_sizes]
+        self._ck(self._lib.alfd_download_solution(self._h, _blocks(x)))
+        return x
+
+    def history(self):
+        cnt = C.c_int32(0)
+        self._lib.alfd_get_history(self._h, None, 0, C.byref(cnt))
+        out = np.zeros(max(cnt.value, 1))
+        self._lib.alfd_get_history(self._h, out.ctypes.data, cnt.value, C.byref(cnt))
+        return out[:cnt.value]
+
+    # -- primitives
+    def spmv(self, slot, x, y=None, mode=0, alpha=1.0):
+        x = np.ascontiguousarray(x, np.float64)
+        lanes = C.c_int32()
+        self._ck(self._lib.alfd_matrix_lanes(self._h, slot, C.byref(lanes)))
+        if y is None:
+            raise ValueError("pass y (its length is the row count)")
+        y = np.ascontiguousarray(y, np.float64).copy()
+        self._ck(self._lib.alfd_spmv(self._h, slot, x.ctypes.data, y.ctypes.data, mode, alpha))
+        return y, lanes.value
+
+    def dot(self, x, y):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.ascontiguousarray(y, np.float64)
+        out = C.c_double()
+        self._ck(self._lib.alfd_dot(self._h, x.size, x.ctypes.data, y.ctypes.data, C.byref(out)))
+        return out.value
+
+    def bench_spmv(self, slot, reps=20):
+        ms, nbytes = C.c_double(), C.c_double()
+        self._ck(self._lib.alfd_bench_spmv(self._h, slot, reps, C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
+
+    def enable_timing(self, on=True):
+        self._ck(self._lib.alfd_enable_timing(self._h, int(on)))
+
+    def timing(self):
+        ms = np.zeros(_abi.T_NCLASSES)
+        n = np.zeros(_abi.T_NCLASSES, np.int64)
+        b = np.zeros(_abi.T_NCLASSES)
+        self._ck(self._lib.alfd_get_timing(self._h, ms.ctypes.data, n.ctypes.data, b.ctypes.data))
+        names = ["spmv_A", "spmv_other", "dot", "vec"]
+        return {k: dict(ms=float(ms[i]), launches=int(n[i]), bytes=float(b[i])) for i, k in enumerate(names)}
+
+
+def context_from_problem(pb, cfg: _abi.Config, device_id=0) -> Context:
+    """Upload a problems.SyntheticProblem with the reference's diagonal choices:
+    W^-1 = 1/M_ii^2 (stokes...:976-978), lumped pressure mass (stokes...:946-954)."""
+    ctx = Context(device_id)
+    ctx.set_matrix(_abi.A, pb.mats["A"])
+    ctx.set_matrix(_abi.CT, pb.mats["Ct"])
+    ctx.set_matrix(_abi.C_, pb.mats["C"])
+    ctx.set_diag(_abi.INVW, pb.inv_w_diag_squared())
+    if "B" in pb.mats:
+        ctx.set_matrix(_abi.BT, pb.mats["Bt"])
+        ctx.set_matrix(_abi.B, pb.mats["B"])
+        ctx.set_matrix(_abi.MP, pb.mats["Mp"])
+        ctx.set_diag(_abi.MP_LUMPED_INV, pb.mp_lumped_inv())
+    ctx.configure(cfg)
+    ctx.setup(pb.block_sizes)
+    return ctx
+
+
+# ---------------------------------------------------------------------------
+# Reference-shaped front-ends.  A BlockVector is a list of numpy arrays.
+class _ALPreconditionerBase:
+    variant = None
+
+    def __init__(self, ctx: Context):
+        if ctx.cfg is None or ctx.cfg.variant != self.variant:
+            raise ValueError("context is configured for a different preconditioner variant")
+        self.ctx = ctx
+        self.last_result = None
+
+    def vmult(self, dst, src):
+        """void vmult(BlockVector<double>& v, const BlockVector<double>& u) const"""
+        out, self.last_result = self.ctx.precond_apply(src)
+        for d, o in zip(dst, out):
+            d[...] = o
+
+
+class BlockPreconditionerAugmentedLagrangian(_ALPreconditionerBase):
+    """augmented_lagrangian_preconditioner.h:14-42."""
+    variant = _abi.AL2
+
+
+class BlockPreconditionerAugmentedLagrangianStokes(_ALPreconditionerBase):
+    """augmented_lagrangian_preconditioner.h:44-79."""
+    variant = _abi.AL_STOKES
+
+
+class BlockPreconditionerAugmentedLagrangianDiagonal(_ALPreconditionerBase):
+    """augmented_lagrangian_preconditioner.h:81-110."""
+    variant = _abi.AL_STOKES_DIAG
+
+
+class SystemOperator:
+    """The block_operator AA (stokes_immersed_boundary.cc:1000-1003)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def vmult(self, dst, src):
+        out = self.ctx.system_apply(src)
+        for d, o in zip(dst, out):
+            d[...] = o
+
+
+class SolverFGMRES:
+    """SolverFGMRES<BlockVector<double>> (stokes_immersed_boundary.cc:1067): the
+    control lives in the context's alfd_config.outer; solve() runs wholly on the GPU."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.last_result = None
+
+    def solve(self, A: SystemOperator, x, b, P: _ALPreconditionerBase):
+        if A.ctx is not self.ctx or P.ctx is not self.ctx:
+            raise ValueError("operator, preconditioner and solver must share one context")
+        sol, self.last_result = self.ctx.solve(b, x0=x)
+        for d, o in zip(x, sol):
+            d[...] = o
+
+    def last_step(self):
+        return self.last_result.outer_iterations

@@ -1,0 +1,248 @@
+/* alfd.h -- C ABI of the MI355X-native augmented-Lagrangian FGMRES solver.
+ *
+ * This is the drop-in boundary.  The reference has no FFI:
+ * its "operator API" is deal.II's duck-typed concept
+ *     void vmult(BlockVector<double>& dst, const BlockVector<double>& src) const
+ * implemented by the preconditioner classes of
+ * augmented_lagrangian_preconditioner.h:28,62,95,130,186 and
+ * rational_preconditioner.h:29, and consumed by
+ *     SolverFGMRES<BlockVector<double>>::solve(AA, x, b, P)
+ * (immersed_laplace.cc:943-944, stokes_immersed_boundary.cc:1073-1074,
+ * elliptic_interface.cc:905-906, 947-948).  Each entry point below says which
+ * of those it replaces.  include/alfd/dealii_adapter.hpp wraps this ABI back
+ * into deal.II-shaped C++ classes; INTEGRATION.md shows the call-site diff.
+ *
+ * Conventions: every call returns an int status (never throws across the
+ * ABI); all pointers at the ABI are HOST pointers -- device residency is
+ * internal; a context is single-threaded (like the reference, which runs
+ * MPI_InitFinalize(argc, argv, 1)); several contexts may coexist.
+ * All floating point data is fp64; column indices are int32, row starts int64
+ * (deal.II: unsigned int columns, std::size_t rowstart).
+ */
+#ifndef ALFD_H
+#define ALFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALFD_ABI_VERSION 1
+#define ALFD_MAX_BLOCKS 3
+
+/* ------------------------------------------------------------------ status */
+enum alfd_status {
+  ALFD_OK = 0,
+  ALFD_E_INVALID = 1,              /* bad argument / inconsistent sizes */
+  ALFD_E_HIP = 2,                  /* a HIP runtime call failed */
+  ALFD_E_NO_CONVERGENCE_OUTER = 3, /* SolverControl::NoConvergence from FGMRES */
+  ALFD_E_NO_CONVERGENCE_INNER = 4, /* ... from an inner CG (stokes...:1020-1024) */
+  ALFD_E_BREAKDOWN = 5,            /* NaN / non-positive curvature */
+  ALFD_E_NOT_SETUP = 6,
+  ALFD_E_COMM = 7,                 /* RCCL failure */
+  ALFD_E_UNSUPPORTED = 8
+};
+
+/* ---------------------------------------------------------------- operators
+ * Matrix slots (square brackets: which reference object it is).
+ *   A    [stokes_matrix.block(0,0) stokes...:923 | stiffness_matrix immersed_laplace.cc:638
+ *         | stiffness_matrix_bg elliptic...:680]
+ *   BT   [stokes_matrix.block(0,1) stokes...:924]   B [block(1,0) :925]
+ *   CT   [coupling_matrix, n_u x n_lambda, stokes...:926, immersed_laplace.cc:640]
+ *   C    optional; when absent alfd_setup() transposes CT (the reference applies
+ *        transpose_operator(Ct), i.e. SparseMatrix::Tvmult -- stokes...:927)
+ *   M    [mass_matrix_immersed stokes...:928 | mass_matrix_fg elliptic...:682]
+ *   MP   [preconditioner_matrix.block(1,1) stokes...:929]
+ *   A2   [stiffness_matrix_fg elliptic...:681]
+ *   KIMM [embedded_stiffness_matrix immersed_laplace.cc:639; rational_preconditioner.h:15]
+ */
+enum alfd_matrix_slot {
+  ALFD_A = 0,
+  ALFD_BT = 1,
+  ALFD_B = 2,
+  ALFD_CT = 3,
+  ALFD_C = 4,
+  ALFD_M = 5,
+  ALFD_MP = 6,
+  ALFD_A2 = 7,
+  ALFD_KIMM = 8,
+  ALFD_NSLOTS = 9
+};
+
+/* Diagonal operators.
+ *   INVW            W^-1 as a vector: 1/M_ii^2 (stokes...:976-978,
+ *                   immersed_laplace.cc:866-869), 1/M_ii (operator form, :856-858),
+ *                   1/(M^2)_ii (utilities.h:348-374, elliptic...:726)
+ *   MP_LUMPED_INV   1/(Mp 1)_i, the preconditioner of the pressure-mass CG
+ *                   (stokes...:946-957)
+ */
+enum alfd_diag_slot { ALFD_INVW = 0, ALFD_MP_LUMPED_INV = 1, ALFD_NDIAGS = 2 };
+
+/* Which preconditioner class / system operator pair is configured. */
+enum alfd_variant {
+  ALFD_AL2 = 0,            /* BlockPreconditionerAugmentedLagrangian, ...preconditioner.h:14-42;
+                              AA = [[Aug,Ct],[C,0]] immersed_laplace.cc:891-892 */
+  ALFD_AL_STOKES = 1,      /* ...Stokes, :44-79; AA 3x3 stokes...:1000-1003 */
+  ALFD_AL_STOKES_DIAG = 2, /* ...Diagonal, :81-110 (SPD, for MinRes) */
+  ALFD_AL_ELL_IDEAL = 3,   /* BlockTriangularALPreconditioner, :115-164 */
+  ALFD_AL_ELL_MODIFIED = 4,/* ...Modified, :168-238; system elliptic...:816-819 */
+  ALFD_RATIONAL = 5        /* RationalPreconditioner, rational_preconditioner.h:12-99 */
+};
+
+/* deal.II stop rules [EXT], SURVEY.md 8(a)-12.
+ *   ABS          SolverControl:        success if r <= tol; failure if k >= max_steps or NaN
+ *   REDUCTION    ReductionControl:     also success if r < reduce * r0
+ *   FIXED_ITERS  IterationNumberControl: success if k >= max_steps (or r <= tol)
+ */
+enum alfd_control_kind { ALFD_CTRL_ABS = 0, ALFD_CTRL_REDUCTION = 1, ALFD_CTRL_FIXED_ITERS = 2 };
+
+typedef struct alfd_control {
+  int32_t kind;
+  int32_t max_steps;
+  double tol;
+  double reduce;
+} alfd_control;
+
+/* Preconditioner of the inner CG on the augmented block.  The reference uses
+ * Trilinos ML (stokes...:1027-1045); north_star replaces it by a Jacobi /
+ * Chebyshev sweep. */
+enum alfd_inner_prec { ALFD_PREC_IDENTITY = 0, ALFD_PREC_JACOBI = 1, ALFD_PREC_CHEBYSHEV = 2 };
+
+/* Arnoldi orthogonalisation in FGMRES [EXT]: deal.II <= 9.5 modified
+ * Gram-Schmidt; >= 9.6 classical Gram-Schmidt variants. */
+enum alfd_orthogonalization { ALFD_ORTH_MGS = 0, ALFD_ORTH_CGS = 1, ALFD_ORTH_CGS2 = 2 };
+
+/* What to do when an inner CG hits max_steps: the reference throws
+ * SolverControl::NoConvergence (THROW); ACCEPT keeps the last iterate. */
+enum alfd_inner_failure_policy { ALFD_INNER_THROW = 0, ALFD_INNER_ACCEPT = 1 };
+
+typedef struct alfd_config {
+  int32_t variant;            /* enum alfd_variant */
+  int32_t restart;            /* FGMRES max_basis_size: 30 default, 50 elliptic...:863 */
+  int32_t orthogonalization;  /* enum alfd_orthogonalization */
+  int32_t grad_div_in_A;      /* 1: A already holds gamma_gd (div,div) (stokes...:991-993) */
+  double gamma;               /* AL parameter (gamma_1 for elliptic) */
+  double gamma_grad_div;      /* stokes...:987 */
+  double gamma2;              /* gamma_2, elliptic...:751-752 */
+  alfd_control outer;         /* outer_solver_control, stokes...:385-389 */
+  alfd_control inner;         /* control_lagrangian, stokes...:1020-1023 */
+  alfd_control mp_inner;      /* control_mass(100, 1e-6), stokes...:934 */
+  int32_t inner_prec;         /* enum alfd_inner_prec */
+  int32_t cheb_degree;        /* polynomial degree k >= 1 */
+  int32_t cheb_power_its;     /* power iterations for lambda_max(D^-1 Aug) */
+  int32_t on_inner_failure;   /* enum alfd_inner_failure_policy */
+  double cheb_eig_ratio;      /* lambda_min = lambda_max / ratio */
+  double cheb_safety;         /* lambda_max *= safety (deal.II uses 1.2) */
+  int32_t log_level;          /* 0 silent; 1 result lines; 2 per-iteration "Check" lines */
+  int32_t reserved;
+} alfd_config;
+
+typedef struct alfd_result {
+  int32_t status;             /* enum alfd_status of the solve */
+  int32_t outer_iterations;   /* SolverControl::last_step(), stokes...:1087 */
+  double initial_residual;
+  double last_residual;       /* SolverControl::last_value() */
+  int64_t inner_iterations;   /* total CG iterations on the augmented block(s) */
+  int64_t mp_iterations;      /* total CG iterations on Mp */
+  int32_t inner_failures;     /* inner solves that hit max_steps (ACCEPT policy) */
+  int32_t precond_applications;
+  double solve_seconds;       /* wall time inside alfd_solve, device-synchronised */
+  double lambda_max;          /* Chebyshev: estimated lambda_max(D^-1 Aug) incl. safety */
+} alfd_result;
+
+typedef struct alfd_ctx *alfd_ctx_t;
+
+/* ---------------------------------------------------------------- lifecycle */
+int alfd_abi_version(void);
+const char *alfd_strerror(int status);
+/* Last error message of a context (HIP error strings etc.). */
+const char *alfd_last_error(alfd_ctx_t ctx);
+
+/* One context = one GPU = one rank.  device_id is the HIP ordinal. */
+int alfd_create(alfd_ctx_t *ctx, int device_id);
+int alfd_destroy(alfd_ctx_t ctx);
+
+/* ------------------------------------------------------- multi-GPU (RCCL)
+ * One process per GPU.  Rank 0 obtains an id with alfd_comm_unique_id(), the
+ * host launcher broadcasts the bytes (bench.py uses torch.distributed), every
+ * rank calls alfd_comm_init().  Without it the context is single-rank.
+ * Row partition: every block b of the block vectors is split in contiguous
+ * row ranges; offsets[b] has nranks+1 entries (global prefix).  Must be set
+ * before matrices are uploaded.  Matrices are then uploaded as LOCAL rows
+ * with GLOBAL column indices. */
+#define ALFD_UNIQUE_ID_BYTES 128
+int alfd_comm_unique_id(void *id_out, size_t bytes);
+int alfd_comm_init(alfd_ctx_t ctx, int rank, int nranks, const void *id, size_t bytes);
+int alfd_set_partition(alfd_ctx_t ctx, int nblocks, const int64_t *const *offsets /*[nblocks][nranks+1]*/);
+
+/* ------------------------------------------------------------------- upload
+ * Replaces: linear_operator(SparseMatrix) captures, stokes...:923-929.
+ * Caller keeps ownership of host arrays; the library copies to HBM.
+ * Rows in CSR order, columns ascending within a row (the adapter converts
+ * deal.II's diagonal-first order).  nrows = local rows, ncols = GLOBAL columns. */
+int alfd_set_matrix(alfd_ctx_t ctx, int slot, int64_t nrows, int64_t ncols, const int64_t *row_ptr,
+                    const int32_t *col, const double *val);
+/* Replaces: DiagonalMatrix<Vector<double>> (stokes...:954, 980). n = local length. */
+int alfd_set_diag(alfd_ctx_t ctx, int slot, int64_t n, const double *d);
+int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg);
+void alfd_default_config(alfd_config *cfg, int variant);
+/* Builds transposes, sparse-row views, diag(Aug), lambda_max, halo plans
+ * (replaces the setup in stokes...:1027-1045 / utilities.h:112-331). */
+int alfd_setup(alfd_ctx_t ctx);
+
+/* --------------------------------------------------------------- hot path
+ * Depth 1. Replaces <Preconditioner>::vmult(dst, src)
+ * (augmented_lagrangian_preconditioner.h:28-34, 62-70, 95-103, 130-156, 185-229).
+ * src/dst: one host pointer per block (local rows). */
+int alfd_precond_apply(alfd_ctx_t ctx, const double *const *src_blocks, double *const *dst_blocks,
+                       alfd_result *res);
+/* Replaces AA.vmult(dst, src): the block system operator (stokes...:1000-1003). */
+int alfd_system_apply(alfd_ctx_t ctx, const double *const *src_blocks, double *const *dst_blocks);
+/* Replaces the rhs augmentation f += gamma Ct invW g (stokes...:1012-1018,
+ * immersed_laplace.cc:900-905): rhs_blocks[0] is updated in place from rhs_blocks[last]. */
+int alfd_augment_rhs(alfd_ctx_t ctx, double *const *rhs_blocks);
+/* Depth 2 (the measured path). Replaces
+ * SolverFGMRES<BlockVector<double>>::solve(AA, x, b, P) (stokes...:1067-1074).
+ * x_blocks: in = initial guess, out = solution. */
+int alfd_solve(alfd_ctx_t ctx, const double *const *rhs_blocks, double *const *x_blocks,
+               alfd_result *res);
+/* Same solve with the vectors already resident in HBM (no PCIe in the timed
+ * region): alfd_upload_rhs() then alfd_solve_resident() any number of times,
+ * alfd_download_solution() at the end. */
+int alfd_upload_rhs(alfd_ctx_t ctx, const double *const *rhs_blocks, const double *const *x0_blocks);
+int alfd_solve_resident(alfd_ctx_t ctx, alfd_result *res);
+int alfd_download_solution(alfd_ctx_t ctx, double *const *x_blocks);
+/* Residual history of the last solve: out[k] = residual checked at step k. */
+int alfd_get_history(alfd_ctx_t ctx, double *out, int32_t capacity, int32_t *count);
+
+/* ------------------------------------------------------------- primitives
+ * The kernels under the solver, callable on host data for parity tests
+ * (SURVEY.md 8(a) a13/a14).  y = A x (mode 0) or y += alpha A x (mode 1). */
+int alfd_spmv(alfd_ctx_t ctx, int slot, const double *x, double *y, int mode, double alpha);
+int alfd_dot(alfd_ctx_t ctx, int64_t n, const double *x, const double *y, double *result);
+/* Lanes per row the canonical SpMV order uses for this slot (after setup). */
+int alfd_matrix_lanes(alfd_ctx_t ctx, int slot, int32_t *lanes);
+/* Benchmark hook: run `reps` back-to-back y = A x launches of `slot` on resident
+ * device data and return the mean kernel time in ms measured with HIP events on
+ * the library's stream, plus the algorithmic bytes of one launch. */
+int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launch,
+                    double *algorithmic_bytes);
+/* Kernel-class timing of the last solve, accumulated with HIP events when
+ * alfd_enable_timing(ctx, 1) was called before: class ids in alfd_timing_class. */
+enum alfd_timing_class {
+  ALFD_T_SPMV_A = 0,
+  ALFD_T_SPMV_OTHER = 1,
+  ALFD_T_DOT = 2,
+  ALFD_T_VEC = 3,
+  ALFD_T_NCLASSES = 4
+};
+int alfd_enable_timing(alfd_ctx_t ctx, int on);
+int alfd_get_timing(alfd_ctx_t ctx, double *ms /*[ALFD_T_NCLASSES]*/, int64_t *launches /*[..]*/,
+                    double *algorithmic_bytes /*[..]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALFD_H */

@@ -1,0 +1,766 @@
+// alfd_oracle.cpp -- CPU ORACLE (test infrastructure, NOT product code).
+//
+// PARITY STATUS: "parity unpinned" with respect to a real deal.II+Trilinos run.
+// The reference cannot be built here (deal.II, Trilinos ML, UMFPACK absent --
+// SURVEY.md 8(c)) and ships no golden vectors for the AL path, so this file is
+// a restatement of the reference's algorithm pinned only by (i) independent
+// SciPy cross-checks in tests/ and (ii) the rational-approximation constants of
+// rational_preconditioner.h:70-93.  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load this library.
+//
+// What it restates (reference file:line):
+//   * preconditioner algebra, verbatim order of operations:
+//       augmented_lagrangian_preconditioner.h:28-34 (AL2), :62-70 (Stokes),
+//       :95-103 (diagonal SPD), :225-228 (elliptic modified)
+//   * operator composition / tolerances:
+//       immersed_laplace.cc:880-916, stokes_immersed_boundary.cc:931-1054
+//   * [EXT] deal.II algorithms written from their published descriptions:
+//       SolverCG (zero initial guess through inverse_operator), SolverFGMRES
+//       (9.6-style: check + ++k after every Arnoldi step, Givens), SolverControl /
+//       ReductionControl / IterationNumberControl stop rules.
+//   * the inner preconditioner named by north_star (Jacobi / Chebyshev sweep on
+//       D^-1 Aug) in place of Trilinos ML (stokes...:1027-1045).
+//
+// Canonical arithmetic ("ALFD-arith v1"): every reduction
+// has a fixed tree so that the HIP kernels can reproduce it bit for bit.
+//   SpMV row (L lanes, V per lane): lane l accumulates entries
+//       k0 + (m*L + l)*V + v  (m = 0,1,..; v = 0..V-1) with fma, then a binary
+//       tree lane[l] += lane[l+s], s = L/2..1.
+//   dot: 4096-element chunks; thread t of 256 accumulates elements
+//       base + e*512 + 2t, +1 (e = 0..7) with fma; 64-lane tree; 4 wave sums
+//       combined as (w0+w1)+(w2+w3); chunk partials reduced by one more such
+//       block (thread-strided sequential adds).
+//   multi-rank: local dots summed in rank order.
+// Compile with -ffp-contract=off; fma only where written.
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "alfd/alfd.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace orc {
+
+constexpr int64_t CHUNK = 4096;  // dot chunk = block-vector padding granule
+
+struct Csr {
+  int64_t nrows = 0, ncols = 0;
+  const int64_t *rp = nullptr;
+  const int32_t *col = nullptr;
+  const double *val = nullptr;
+  int L = 64, V = 1;
+  std::vector<int64_t> own_rp;  // storage when built internally (transpose)
+  std::vector<int32_t> own_col;
+  std::vector<double> own_val;
+  bool present() const { return rp != nullptr; }
+  int64_t nnz() const { return rp ? rp[nrows] : 0; }
+};
+
+// Lanes-per-row rule shared (by specification) with the HIP library:
+// mean nnz over NON-EMPTY rows.
+inline void choose_lanes(Csr &m) {
+  int64_t nonempty = 0;
+  for (int64_t r = 0; r < m.nrows; ++r) nonempty += (m.rp[r + 1] > m.rp[r]);
+  const double avg = nonempty ? (double)m.nnz() / (double)nonempty : 0.0;
+  m.V = 1;
+  if (avg > 48)
+    m.L = 64;
+  else if (avg > 24)
+    m.L = 32;
+  else if (avg > 12)
+    m.L = 16;
+  else if (avg > 6)
+    m.L = 8;
+  else
+    m.L = 4;
+}
+
+inline double row_sum(const Csr &m, int64_t r, const double *x) {
+  double lane[64];
+  const int64_t k0 = m.rp[r], k1 = m.rp[r + 1];
+  const int L = m.L, V = m.V;
+  for (int l = 0; l < L; ++l) {
+    double acc = 0.0;
+    for (int64_t k = k0 + (int64_t)l * V; k < k1; k += (int64_t)L * V)
+      for (int v = 0; v < V && k + v < k1; ++v) acc = std::fma(m.val[k + v], x[m.col[k + v]], acc);
+    lane[l] = acc;
+  }
+  for (int s = L / 2; s >= 1; s >>= 1)
+    for (int l = 0; l < s; ++l) lane[l] = lane[l] + lane[l + s];
+  return lane[0];
+}
+
+// mode 0: y = A x ; mode 1: y = fma(alpha, A x, y)
+void spmv(const Csr &m, const double *x, double *y, int mode, double alpha) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < m.nrows; ++r) {
+    if (mode == 1 && m.rp[r + 1] == m.rp[r]) continue;  // empty row: y unchanged
+    const double s = row_sum(m, r, x);
+    y[r] = mode == 0 ? s : std::fma(alpha, s, y[r]);
+  }
+}
+
+inline double tree256(double *lane) {  // 4 waves of 64, then (w0+w1)+(w2+w3)
+  double w[4];
+  for (int wv = 0; wv < 4; ++wv) {
+    double *a = lane + 64 * wv;
+    for (int s = 32; s >= 1; s >>= 1)
+      for (int l = 0; l < s; ++l) a[l] = a[l] + a[l + s];
+    w[wv] = a[0];
+  }
+  return (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+double dot(int64_t n, const double *x, const double *y) {
+  if (n <= 0) return 0.0;
+  const int64_t nb = (n + CHUNK - 1) / CHUNK;
+  std::vector<double> part(nb);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < nb; ++b) {
+    double lane[256];
+    const int64_t base = b * CHUNK;
+    for (int t = 0; t < 256; ++t) {
+      double acc = 0.0;
+      for (int e = 0; e < 8; ++e) {
+        const int64_t i = base + e * 512 + 2 * t;
+        if (i < n) acc = std::fma(x[i], y[i], acc);
+        if (i + 1 < n) acc = std::fma(x[i + 1], y[i + 1], acc);
+      }
+      lane[t] = acc;
+    }
+    part[b] = tree256(lane);
+  }
+  double lane[256];
+  for (int t = 0; t < 256; ++t) {
+    double acc = 0.0;
+    for (int64_t i = t; i < nb; i += 256) acc = acc + part[i];
+    lane[t] = acc;
+  }
+  return tree256(lane);
+}
+
+// ---- elementwise (padding entries are zero and stay zero)
+inline void axpy(int64_t n, double a, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] = std::fma(a, x[i], y[i]);
+}
+inline void xpby(int64_t n, const double *x, double b, double *y) {  // y = x + b y
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] = std::fma(b, y[i], x[i]);
+}
+inline void scale(int64_t n, double a, double *x) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) x[i] = a * x[i];
+}
+inline void pmul(int64_t n, const double *d, const double *x, double *y) {  // y = d .* x
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] = d[i] * x[i];
+}
+inline void pmul_scale(int64_t n, double a, const double *d, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) y[i] = a * (d[i] * x[i]);  // y = a (d .* x)
+}
+inline void sub_from(int64_t n, const double *b, double *v) {  // v = b - v
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) v[i] = b[i] - v[i];
+}
+
+// ------------------------------------------------------------ stop rules
+enum State { ITERATE = 0, SUCCESS = 1, FAILURE = 2 };
+struct Control {
+  alfd_control c;
+  double initial = 0, reduced_tol = 0, last_value = 0;
+  int last_step = 0;
+  State check(int step, double v) {
+    last_step = step;
+    last_value = v;
+    if (step == 0) {
+      initial = v;
+      reduced_tol = v * c.reduce;
+    }
+    if (c.kind == ALFD_CTRL_REDUCTION && v < reduced_tol) return SUCCESS;
+    if (c.kind == ALFD_CTRL_FIXED_ITERS && step >= c.max_steps) return SUCCESS;
+    if (v <= c.tol) return SUCCESS;
+    if (step >= c.max_steps || std::isnan(v)) return FAILURE;
+    return ITERATE;
+  }
+};
+
+// --------------------------------------------------------------- problem
+struct Problem {
+  Csr mat[ALFD_NSLOTS];
+  const double *diag[ALFD_NDIAGS] = {nullptr, nullptr};
+  int nblocks = 0;
+  int64_t n[ALFD_MAX_BLOCKS] = {0, 0, 0};
+  int64_t off[ALFD_MAX_BLOCKS + 1] = {0, 0, 0, 0};  // padded offsets
+  alfd_config cfg;
+  // setup products
+  std::vector<double> dinv_aug;  // 1/diag(Aug)
+  double lambda_max = 0, lambda_min = 0;
+  // stats
+  int64_t inner_its = 0, mp_its = 0;
+  int inner_failures = 0, precond_applications = 0;
+  int status = ALFD_OK;
+  int64_t ntot() const { return off[nblocks]; }
+};
+
+static void transpose_into(const Csr &a, Csr &t) {
+  t.nrows = a.ncols;
+  t.ncols = a.nrows;
+  t.own_rp.assign(t.nrows + 1, 0);
+  const int64_t nnz = a.nnz();
+  t.own_col.resize(nnz);
+  t.own_val.resize(nnz);
+  for (int64_t k = 0; k < nnz; ++k) t.own_rp[a.col[k] + 1]++;
+  for (int64_t r = 0; r < t.nrows; ++r) t.own_rp[r + 1] += t.own_rp[r];
+  std::vector<int64_t> cur(t.own_rp.begin(), t.own_rp.end() - 1);
+  for (int64_t r = 0; r < a.nrows; ++r)
+    for (int64_t k = a.rp[r]; k < a.rp[r + 1]; ++k) {
+      const int64_t p = cur[a.col[k]]++;
+      t.own_col[p] = (int32_t)r;
+      t.own_val[p] = a.val[k];
+    }
+  t.rp = t.own_rp.data();
+  t.col = t.own_col.data();
+  t.val = t.own_val.data();
+}
+
+// Aug x = A x + gamma Ct (w .* (C x))   (stokes...:991-993, immersed_laplace.cc:883)
+static void aug_apply(Problem &P, const double *x, double *y, std::vector<double> &t) {
+  const Csr &A = P.mat[ALFD_A], &Ct = P.mat[ALFD_CT], &C = P.mat[ALFD_C];
+  spmv(A, x, y, 0, 0.0);
+  t.resize(C.nrows);
+  spmv(C, x, t.data(), 0, 0.0);
+  pmul(C.nrows, P.diag[ALFD_INVW], t.data(), t.data());
+  spmv(Ct, t.data(), y, 1, P.cfg.gamma);
+}
+
+struct AugOp {
+  Problem &P;
+  std::vector<double> t;
+  void operator()(const double *x, double *y) { aug_apply(P, x, y, t); }
+  int64_t n() const { return P.n[0]; }
+};
+struct MatOp {
+  const Csr &m;
+  void operator()(const double *x, double *y) { spmv(m, x, y, 0, 0.0); }
+  int64_t n() const { return m.nrows; }
+};
+
+// Preconditioners of the inner CG.
+struct IdentityPrec {
+  void operator()(const double *r, double *z, int64_t n) { std::memcpy(z, r, n * sizeof(double)); }
+};
+struct DiagPrec {
+  const double *dinv;
+  void operator()(const double *r, double *z, int64_t n) { pmul(n, dinv, r, z); }
+};
+// Chebyshev polynomial of degree k in D^-1 Aug (Saad, Alg. 12.1, zero start).
+struct ChebPrec {
+  Problem &P;
+  AugOp &op;
+  std::vector<double> d, res, tmp;
+  void operator()(const double *r, double *z, int64_t n) {
+    const double lmax = P.lambda_max, lmin = P.lambda_min;
+    const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+    const double sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    const double *dinv = P.dinv_aug.data();
+    d.resize(n);
+    res.resize(n);
+    tmp.resize(n);
+    const double inv_theta = 1.0 / theta;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      d[i] = inv_theta * (dinv[i] * r[i]);
+      z[i] = d[i];
+    }
+    if (P.cfg.cheb_degree > 1) std::memcpy(res.data(), r, n * sizeof(double));
+    for (int j = 1; j < P.cfg.cheb_degree; ++j) {
+      op(d.data(), tmp.data());  // tmp = Aug d
+      const double rho_new = 1.0 / (2.0 * sigma - rho);
+      const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; ++i) {
+        res[i] = res[i] - tmp[i];
+        d[i] = std::fma(c1, d[i], c2 * (dinv[i] * res[i]));
+        z[i] = z[i] + d[i];
+      }
+      rho = rho_new;
+    }
+  }
+};
+
+// deal.II SolverCG through inverse_operator: zero initial guess [EXT].
+template <class Op, class Prec>
+static State pcg(Op &op, Prec &prec, const alfd_control &ctrl, const double *b, double *x, int64_t n,
+                 int &its, double &last_res, int log_level, const char *tag) {
+  std::vector<double> r(b, b + n), z(n), p(n), Ap(n);
+  std::fill(x, x + n, 0.0);
+  Control sc{ctrl};
+  double res = std::sqrt(dot(n, r.data(), r.data()));
+  State st = sc.check(0, res);
+  its = 0;
+  double rz_old = 0.0;
+  while (st == ITERATE) {
+    ++its;
+    prec(r.data(), z.data(), n);
+    const double rz = dot(n, r.data(), z.data());
+    if (its > 1) {
+      const double beta = rz / rz_old;
+      xpby(n, z.data(), beta, p.data());
+    } else {
+      std::memcpy(p.data(), z.data(), n * sizeof(double));
+    }
+    op(p.data(), Ap.data());
+    const double pAp = dot(n, p.data(), Ap.data());
+    const double alpha = rz / pAp;
+    axpy(n, alpha, p.data(), x);
+    axpy(n, -alpha, Ap.data(), r.data());
+    res = std::sqrt(dot(n, r.data(), r.data()));
+    st = sc.check(its, res);
+    rz_old = rz;
+    if (log_level >= 3) std::printf("DEAL:%s:cg::Check %d\t%.17g\n", tag, its, res);
+  }
+  last_res = res;
+  return st;
+}
+
+static int inner_solve_aug(Problem &P, const double *b, double *x) {
+  AugOp op{P, {}};
+  int its = 0;
+  double res = 0;
+  State st;
+  const int64_t n = P.n[0];
+  if (P.cfg.inner_prec == ALFD_PREC_IDENTITY) {
+    IdentityPrec pr;
+    st = pcg(op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
+  } else if (P.cfg.inner_prec == ALFD_PREC_JACOBI) {
+    DiagPrec pr{P.dinv_aug.data()};
+    st = pcg(op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
+  } else {
+    AugOp op2{P, {}};
+    ChebPrec pr{P, op2, {}, {}, {}};
+    st = pcg(op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
+  }
+  P.inner_its += its;
+  if (st == FAILURE) {
+    if (std::isnan(res)) return ALFD_E_BREAKDOWN;
+    if (P.cfg.on_inner_failure == ALFD_INNER_THROW) return ALFD_E_NO_CONVERGENCE_INNER;
+    P.inner_failures++;
+  }
+  return ALFD_OK;
+}
+
+static int inner_solve_mp(Problem &P, const double *b, double *x) {
+  MatOp op{P.mat[ALFD_MP]};
+  DiagPrec pr{P.diag[ALFD_MP_LUMPED_INV]};
+  int its = 0;
+  double res = 0;
+  State st = pcg(op, pr, P.cfg.mp_inner, b, x, P.n[1], its, res, P.cfg.log_level, "mp");
+  P.mp_its += its;
+  if (st == FAILURE) {
+    if (std::isnan(res)) return ALFD_E_BREAKDOWN;
+    if (P.cfg.on_inner_failure == ALFD_INNER_THROW) return ALFD_E_NO_CONVERGENCE_INNER;
+    P.inner_failures++;
+  }
+  return ALFD_OK;
+}
+
+// diag(Aug)_i = A_ii + gamma sum_k w_k Ct_ik^2 (sequential fma over the row of
+// Ct); lambda_max(D^-1 Aug) by power iteration from a
+// deterministic integer-hash start vector.
+static void setup(Problem &P) {
+  const Csr &A = P.mat[ALFD_A], &Ct = P.mat[ALFD_CT];
+  const int64_t n = P.n[0];
+  P.dinv_aug.assign(n, 0.0);
+  const double *w = P.diag[ALFD_INVW];
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    double d = 0.0;
+    for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k)
+      if (A.col[k] == i) d = A.val[k];
+    double s = 0.0;
+    for (int64_t k = Ct.rp[i]; k < Ct.rp[i + 1]; ++k) s = std::fma(w[Ct.col[k]] * Ct.val[k], Ct.val[k], s);
+    P.dinv_aug[i] = 1.0 / std::fma(P.cfg.gamma, s, d);
+  }
+  P.lambda_max = P.lambda_min = 0.0;
+  if (P.cfg.inner_prec == ALFD_PREC_CHEBYSHEV) {
+    std::vector<double> v(n), wv(n);
+    for (int64_t i = 0; i < n; ++i)
+      v[i] = 1.0 + (double)(((uint64_t)i * 2654435761ull) & 1023ull) * (1.0 / 1024.0);
+    AugOp op{P, {}};
+    double lam = 0.0;
+    for (int it = 0; it < P.cfg.cheb_power_its; ++it) {
+      const double nv = std::sqrt(dot(n, v.data(), v.data()));
+      scale(n, 1.0 / nv, v.data());
+      op(v.data(), wv.data());
+      pmul(n, P.dinv_aug.data(), wv.data(), wv.data());
+      lam = std::sqrt(dot(n, wv.data(), wv.data()));
+      v.swap(wv);
+    }
+    P.lambda_max = lam * P.cfg.cheb_safety;
+    P.lambda_min = P.lambda_max / P.cfg.cheb_eig_ratio;
+  }
+}
+
+// ------------------------------------------------- preconditioner vmult
+// u, v: padded concatenated block vectors.
+static int precond_apply(Problem &P, const double *u, double *v) {
+  P.precond_applications++;
+  const alfd_config &c = P.cfg;
+  const double *w = P.diag[ALFD_INVW];
+  std::fill(v, v + P.ntot(), 0.0);
+  if (c.variant == ALFD_AL2) {
+    // augmented_lagrangian_preconditioner.h:28-34
+    const double *u0 = u + P.off[0], *u1 = u + P.off[1];
+    double *v0 = v + P.off[0], *v1 = v + P.off[1];
+    pmul_scale(P.n[1], -c.gamma, w, u1, v1);            // v1 = -gamma invW u1
+    std::vector<double> tmp(u0, u0 + P.n[0]);
+    spmv(P.mat[ALFD_CT], v1, tmp.data(), 1, -1.0);      // tmp = u0 - Ct v1
+    return inner_solve_aug(P, tmp.data(), v0);          // v0 = Aug_inv tmp
+  }
+  if (c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG) {
+    // :62-70 (triangular) and :95-103 (diagonal SPD)
+    const bool tri = c.variant == ALFD_AL_STOKES;
+    const double sgn = tri ? -1.0 : 1.0;
+    const double *u0 = u + P.off[0], *u1 = u + P.off[1], *u2 = u + P.off[2];
+    double *v0 = v + P.off[0], *v1 = v + P.off[1], *v2 = v + P.off[2];
+    pmul_scale(P.n[2], sgn * c.gamma, w, u2, v2);       // v2 = -+gamma invW u2
+    std::vector<double> q(P.n[1]);
+    int rc = inner_solve_mp(P, u1, q.data());           // Mp_inv u1
+    if (rc != ALFD_OK) return rc;
+    const double s1 = sgn * c.gamma_grad_div;
+    for (int64_t i = 0; i < P.n[1]; ++i) v1[i] = s1 * q[i];
+    std::vector<double> tmp(u0, u0 + P.n[0]);
+    if (tri) {
+      spmv(P.mat[ALFD_BT], v1, tmp.data(), 1, -1.0);    // - Bt v1
+      spmv(P.mat[ALFD_CT], v2, tmp.data(), 1, -1.0);    // - Ct v2
+    }
+    return inner_solve_aug(P, tmp.data(), v0);
+  }
+  return ALFD_E_UNSUPPORTED;
+}
+
+// AA y = ... (immersed_laplace.cc:891-892, stokes...:1000-1003)
+static int system_apply(Problem &P, const double *x, double *y) {
+  const alfd_config &c = P.cfg;
+  std::fill(y, y + P.ntot(), 0.0);
+  const double *w = P.diag[ALFD_INVW];
+  const int last = P.nblocks - 1;
+  if (c.variant == ALFD_AL2 || c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG) {
+    const double *x0 = x + P.off[0], *xl = x + P.off[last];
+    double *y0 = y + P.off[0], *yl = y + P.off[last];
+    const Csr &C = P.mat[ALFD_C];
+    spmv(P.mat[ALFD_A], x0, y0, 0, 0.0);
+    spmv(C, x0, yl, 0, 0.0);                            // y_lambda = C x0
+    std::vector<double> t(C.nrows);
+    pmul(C.nrows, w, yl, t.data());
+    spmv(P.mat[ALFD_CT], t.data(), y0, 1, c.gamma);     // + gamma Ct invW C x0
+    if (P.nblocks == 3) {
+      spmv(P.mat[ALFD_BT], x + P.off[1], y0, 1, 1.0);   // + Bt x1
+      spmv(P.mat[ALFD_B], x0, y + P.off[1], 0, 0.0);    // y1 = B x0
+    }
+    spmv(P.mat[ALFD_CT], xl, y0, 1, 1.0);               // + Ct x_lambda
+    return ALFD_OK;
+  }
+  return ALFD_E_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------ FGMRES
+// nranks_emul > 1: dots are summed per emulated rank (contiguous equal row
+// split of every block, chunk-aligned local layouts), in rank order.
+struct Partition {
+  int nranks = 1;
+  std::vector<std::vector<int64_t>> offs;  // [block][nranks+1]
+};
+
+static double pdot(const Problem &P, const Partition &pt, const double *x, const double *y) {
+  if (pt.nranks <= 1) return dot(P.ntot(), x, y);
+  double total = 0.0;
+  for (int r = 0; r < pt.nranks; ++r) {
+    // build the rank's padded local vectors
+    int64_t loc_off[ALFD_MAX_BLOCKS + 1] = {0, 0, 0, 0};
+    for (int b = 0; b < P.nblocks; ++b) {
+      const int64_t nl = pt.offs[b][r + 1] - pt.offs[b][r];
+      loc_off[b + 1] = (loc_off[b] + nl + CHUNK - 1) / CHUNK * CHUNK;
+    }
+    std::vector<double> lx(loc_off[P.nblocks], 0.0), ly(loc_off[P.nblocks], 0.0);
+    for (int b = 0; b < P.nblocks; ++b) {
+      const int64_t g0 = pt.offs[b][r], nl = pt.offs[b][r + 1] - g0;
+      std::memcpy(&lx[loc_off[b]], x + P.off[b] + g0, nl * sizeof(double));
+      std::memcpy(&ly[loc_off[b]], y + P.off[b] + g0, nl * sizeof(double));
+    }
+    const double d = dot(loc_off[P.nblocks], lx.data(), ly.data());
+    total = r == 0 ? d : total + d;
+  }
+  return total;
+}
+
+static int fgmres(Problem &P, const Partition &pt, const double *b, double *x, alfd_result *out,
+                  std::vector<double> &history) {
+  const alfd_config &c = P.cfg;
+  const int m = c.restart;
+  const int64_t N = P.ntot();
+  std::vector<std::vector<double>> V(m + 1, std::vector<double>(N)), Z(m, std::vector<double>(N));
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), h(m + 2), h2(m + 2), y(m);
+  Control sc{c.outer};
+  int k = 0;
+  State st = ITERATE;
+  double res = 0;
+  history.clear();
+  do {
+    int rc = system_apply(P, x, V[0].data());
+    if (rc != ALFD_OK) return rc;
+    sub_from(N, b, V[0].data());  // v0 = b - AA x
+    res = std::sqrt(pdot(P, pt, V[0].data(), V[0].data()));
+    st = sc.check(k, res);
+    if (k == 0) history.push_back(res);
+    if (c.log_level >= 2) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
+    if (st != ITERATE) break;
+    if (res != 0.0) scale(N, 1.0 / res, V[0].data());
+    g[0] = res;
+    int j = 0;
+    for (; j < m && st == ITERATE; ++j) {
+      rc = precond_apply(P, V[j].data(), Z[j].data());
+      if (rc != ALFD_OK) return rc;
+      double *wv = V[j + 1].data();
+      rc = system_apply(P, Z[j].data(), wv);
+      if (rc != ALFD_OK) return rc;
+      // orthogonalise wv against V[0..j]
+      if (c.orthogonalization == ALFD_ORTH_MGS) {
+        for (int i = 0; i <= j; ++i) {
+          h[i] = pdot(P, pt, V[i].data(), wv);
+          axpy(N, -h[i], V[i].data(), wv);
+        }
+      } else {
+        for (int i = 0; i <= j; ++i) h[i] = pdot(P, pt, V[i].data(), wv);
+        for (int i = 0; i <= j; ++i) axpy(N, -h[i], V[i].data(), wv);
+        if (c.orthogonalization == ALFD_ORTH_CGS2) {
+          for (int i = 0; i <= j; ++i) h2[i] = pdot(P, pt, V[i].data(), wv);
+          for (int i = 0; i <= j; ++i) axpy(N, -h2[i], V[i].data(), wv);
+          for (int i = 0; i <= j; ++i) h[i] = h[i] + h2[i];
+        }
+      }
+      h[j + 1] = std::sqrt(pdot(P, pt, wv, wv));
+      if (h[j + 1] != 0.0) scale(N, 1.0 / h[j + 1], wv);
+      // Givens
+      for (int i = 0; i < j; ++i) {
+        const double t = cs[i] * h[i] + sn[i] * h[i + 1];
+        h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+        h[i] = t;
+      }
+      const double denom = std::sqrt(h[j] * h[j] + h[j + 1] * h[j + 1]);
+      cs[j] = h[j] / denom;
+      sn[j] = h[j + 1] / denom;
+      h[j] = denom;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = h[i];
+      res = std::fabs(g[j + 1]);
+      ++k;
+      st = sc.check(k, res);
+      history.push_back(res);
+      if (c.log_level >= 2) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
+    }
+    // back substitution, x += Z y
+    for (int i = j - 1; i >= 0; --i) {
+      double s = g[i];
+      for (int l = i + 1; l < j; ++l) s -= H[(size_t)i * m + l] * y[l];
+      y[i] = s / H[(size_t)i * m + i];
+    }
+    for (int i = 0; i < j; ++i) axpy(N, y[i], Z[i].data(), x);
+  } while (st == ITERATE);
+  out->outer_iterations = k;
+  out->initial_residual = sc.initial;
+  out->last_residual = res;
+  if (c.log_level >= 1)
+    std::printf(st == SUCCESS ? "DEAL:FGMRES::Convergence step %d value %.17g\n"
+                              : "DEAL:FGMRES::Failure step %d value %.17g\n",
+                k, res);
+  if (st != SUCCESS) return std::isnan(res) ? ALFD_E_BREAKDOWN : ALFD_E_NO_CONVERGENCE_OUTER;
+  return ALFD_OK;
+}
+
+}  // namespace orc
+
+// ------------------------------------------------------------------- C API
+extern "C" {
+
+typedef struct orc_csr {
+  int64_t nrows, ncols;
+  const int64_t *row_ptr;
+  const int32_t *col;
+  const double *val;
+} orc_csr;
+
+typedef struct orc_problem {
+  orc_csr mat[ALFD_NSLOTS];
+  const double *diag[ALFD_NDIAGS];
+  int32_t nblocks;
+  int32_t nranks_emulated;
+  int64_t n[ALFD_MAX_BLOCKS];
+} orc_problem;
+
+static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P) {
+  P.cfg = *cfg;
+  P.nblocks = op->nblocks;
+  if (P.nblocks < 2 || P.nblocks > 3) return ALFD_E_INVALID;
+  for (int b = 0; b < P.nblocks; ++b) {
+    P.n[b] = op->n[b];
+    P.off[b + 1] = (P.off[b] + P.n[b] + orc::CHUNK - 1) / orc::CHUNK * orc::CHUNK;
+  }
+  for (int s = 0; s < ALFD_NSLOTS; ++s) {
+    orc::Csr &m = P.mat[s];
+    m.nrows = op->mat[s].nrows;
+    m.ncols = op->mat[s].ncols;
+    m.rp = op->mat[s].row_ptr;
+    m.col = op->mat[s].col;
+    m.val = op->mat[s].val;
+  }
+  for (int d = 0; d < ALFD_NDIAGS; ++d) P.diag[d] = op->diag[d];
+  if (!P.mat[ALFD_A].present() || !P.mat[ALFD_CT].present() || !P.diag[ALFD_INVW]) return ALFD_E_INVALID;
+  if (!P.mat[ALFD_C].present()) orc::transpose_into(P.mat[ALFD_CT], P.mat[ALFD_C]);
+  if (P.nblocks == 3) {
+    if (!P.mat[ALFD_BT].present() || !P.mat[ALFD_MP].present() || !P.diag[ALFD_MP_LUMPED_INV])
+      return ALFD_E_INVALID;
+    if (!P.mat[ALFD_B].present()) orc::transpose_into(P.mat[ALFD_BT], P.mat[ALFD_B]);
+  }
+  for (int s = 0; s < ALFD_NSLOTS; ++s)
+    if (P.mat[s].present()) orc::choose_lanes(P.mat[s]);
+  orc::setup(P);
+  return ALFD_OK;
+}
+
+static void pack(const orc::Problem &P, const double *const *blocks, std::vector<double> &v) {
+  v.assign(P.ntot(), 0.0);
+  for (int b = 0; b < P.nblocks; ++b) std::memcpy(&v[P.off[b]], blocks[b], P.n[b] * sizeof(double));
+}
+static void unpack(const orc::Problem &P, const std::vector<double> &v, double *const *blocks) {
+  for (int b = 0; b < P.nblocks; ++b) std::memcpy(blocks[b], &v[P.off[b]], P.n[b] * sizeof(double));
+}
+
+static void fill_result(const orc::Problem &P, alfd_result *res, int status) {
+  res->status = status;
+  res->inner_iterations = P.inner_its;
+  res->mp_iterations = P.mp_its;
+  res->inner_failures = P.inner_failures;
+  res->precond_applications = P.precond_applications;
+  res->lambda_max = P.lambda_max;
+}
+
+int orc_spmv(const orc_csr *m, int lanes, int vec, const double *x, double *y, int mode, double alpha) {
+  orc::Csr c;
+  c.nrows = m->nrows;
+  c.ncols = m->ncols;
+  c.rp = m->row_ptr;
+  c.col = m->col;
+  c.val = m->val;
+  if (lanes > 0) {
+    c.L = lanes;
+    c.V = vec > 0 ? vec : 1;
+  } else {
+    orc::choose_lanes(c);
+  }
+  orc::spmv(c, x, y, mode, alpha);
+  return c.L;
+}
+
+double orc_dot(int64_t n, const double *x, const double *y) { return orc::dot(n, x, y); }
+
+int orc_precond_apply(const orc_problem *op, const alfd_config *cfg, const double *const *src,
+                      double *const *dst, alfd_result *res) {
+  orc::Problem P;
+  int rc = build(op, cfg, P);
+  if (rc != ALFD_OK) return rc;
+  std::vector<double> u, v(P.ntot(), 0.0);
+  pack(P, src, u);
+  rc = orc::precond_apply(P, u.data(), v.data());
+  unpack(P, v, dst);
+  std::memset(res, 0, sizeof(*res));
+  fill_result(P, res, rc);
+  return rc;
+}
+
+int orc_system_apply(const orc_problem *op, const alfd_config *cfg, const double *const *src,
+                     double *const *dst) {
+  orc::Problem P;
+  int rc = build(op, cfg, P);
+  if (rc != ALFD_OK) return rc;
+  std::vector<double> u, v(P.ntot(), 0.0);
+  pack(P, src, u);
+  rc = orc::system_apply(P, u.data(), v.data());
+  unpack(P, v, dst);
+  return rc;
+}
+
+// b0 += gamma Ct (invW .* g)  (stokes...:1012-1018)
+int orc_augment_rhs(const orc_problem *op, const alfd_config *cfg, double *const *rhs) {
+  orc::Problem P;
+  int rc = build(op, cfg, P);
+  if (rc != ALFD_OK) return rc;
+  const int last = P.nblocks - 1;
+  std::vector<double> t(P.n[last]);
+  orc::pmul(P.n[last], P.diag[ALFD_INVW], rhs[last], t.data());
+  orc::spmv(P.mat[ALFD_CT], t.data(), rhs[0], 1, cfg->gamma);
+  return ALFD_OK;
+}
+
+int orc_solve(const orc_problem *op, const alfd_config *cfg, const double *const *rhs,
+              double *const *x, alfd_result *res, double *history, int32_t history_cap,
+              int32_t *history_count) {
+  orc::Problem P;
+  int rc = build(op, cfg, P);
+  if (rc != ALFD_OK) return rc;
+  orc::Partition pt;
+  pt.nranks = op->nranks_emulated > 1 ? op->nranks_emulated : 1;
+  if (pt.nranks > 1) {
+    pt.offs.resize(P.nblocks);
+    for (int b = 0; b < P.nblocks; ++b) {
+      pt.offs[b].resize(pt.nranks + 1);
+      for (int r = 0; r <= pt.nranks; ++r) pt.offs[b][r] = P.n[b] * r / pt.nranks;
+    }
+  }
+  std::vector<double> bb, xx, hist;
+  pack(P, rhs, bb);
+  pack(P, x, xx);
+  std::memset(res, 0, sizeof(*res));
+  const auto t0 = std::chrono::steady_clock::now();
+  rc = orc::fgmres(P, pt, bb.data(), xx.data(), res, hist);
+  res->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  unpack(P, xx, x);
+  fill_result(P, res, rc);
+  if (history_count) *history_count = (int32_t)hist.size();
+  if (history)
+    for (int i = 0; i < (int)hist.size() && i < history_cap; ++i) history[i] = hist[i];
+  return rc;
+}
+
+// Thread count of the OpenMP loops (results do not depend on it: every row sum
+// and every chunk partial is computed by exactly one thread in canonical order).
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
+// Scalar known-answer hook for a6: evaluates res0 + sum_i res_i / (x - p_i)
+// with the constants of rational_preconditioner.h:70-93 passed in by the test.
+double orc_rational_eval(int npoles, const double *res, const double *poles, double x) {
+  double s = res[0];
+  for (int i = 0; i < npoles; ++i) s += res[i + 1] / (x - poles[i]);
+  return s;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+"""Python front-end of the CPU oracle (oracle/alfd_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from fictitious_domain_al_preconditioners_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+class _Csr(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("row_ptr", C.c_void_p),
+                ("col", C.c_void_p), ("val", C.c_void_p)]
+
+
+class _Problem(C.Structure):
+    _fields_ = [("mat", _Csr * _abi.NSLOTS), ("diag", C.c_void_p * _abi.NDIAGS),
+                ("nblocks", C.c_int32), ("nranks_emulated", C.c_int32),
+                ("n", C.c_int64 * _abi.ALFD_MAX_BLOCKS)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        l = C.CDLL(_LIB)
+        PP = C.POINTER(C.c_void_p)
+        l.orc_spmv.restype = C.c_int
+        l.orc_spmv.argtypes = [C.POINTER(_Csr), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        l.orc_dot.restype = C.c_double
+        l.orc_dot.argtypes = [C.c_int64, C.c_void_p, C.c_void_p]
+        l.orc_precond_apply.restype = C.c_int
+        l.orc_precond_apply.argtypes = [C.POINTER(_Problem), C.POINTER(_abi.Config), PP, PP,
+                                        C.POINTER(_abi.Result)]
+        l.orc_system_apply.restype = C.c_int
+        l.orc_system_apply.argtypes = [C.POINTER(_Problem), C.POINTER(_abi.Config), PP, PP]
+        l.orc_augment_rhs.restype = C.c_int
+        l.orc_augment_rhs.argtypes = [C.POINTER(_Problem), C.POINTER(_abi.Config), PP]
+        l.orc_solve.restype = C.c_int
+        l.orc_solve.argtypes = [C.POINTER(_Problem), C.POINTER(_abi.Config), PP, PP, C.POINTER(_abi.Result),
+                                C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        l.orc_set_threads.restype = C.c_int
+        l.orc_set_threads.argtypes = [C.c_int]
+        l.orc_rational_eval.restype = C.c_double
+        l.orc_rational_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]
+        _lib = l
+    return _lib
+
+
+def set_threads(n: int) -> int:
+    """Set the oracle's OpenMP thread count; returns the count in effect."""
+    return lib().orc_set_threads(int(n))
+
+
+def _csr_struct(m) -> _Csr:
+    return _Csr(m.nrows, m.ncols, m.row_ptr.ctypes.data, m.col.ctypes.data, m.val.ctypes.data)
+
+
+def _blocks(arrs):
+    a = (C.c_void_p * len(arrs))()
+    for i, x in enumerate(arrs):
+        a[i] = x.ctypes.data
+    return a
+
+
+def spmv(m, x, y=None, mode=0, alpha=1.0, lanes=0, vec=1):
+    """Canonical-order CSR SpMV; returns (y, lanes_used)."""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.zeros(m.nrows) if y is None else np.ascontiguousarray(y, np.float64).copy()
+    s = _csr_struct(m)
+    L = lib().orc_spmv(C.byref(s), lanes, vec, x.ctypes.data, y.ctypes.data, mode, alpha)
+    return y, L
+
+
+def dot(x, y):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.ascontiguousarray(y, np.float64)
+    return lib().orc_dot(x.size, x.ctypes.data, y.ctypes.data)
+
+
+class OracleSystem:
+    """One block saddle-point system held by host arrays (kept alive here)."""
+
+    def __init__(self, mats: dict, diags: dict, block_sizes, nranks_emulated=1):
+        self._keep = (mats, diags)
+        self.block_sizes = list(block_sizes)
+        p = _Problem()
+        for name, m in mats.items():
+            p.mat[_abi.SLOT_BY_NAME[name]] = _csr_struct(m)
+        for slot, d in diags.items():
+            d = np.ascontiguousarray(d, np.float64)
+            self._keep += (d,)
+            p.diag[slot] = d.ctypes.data
+        p.nblocks = len(block_sizes)
+        p.nranks_emulated = nranks_emulated
+        for i, n in enumerate(block_sizes):
+            p.n[i] = n
+        self._p = p
+
+    def _check(self, blocks):
+        out = [np.ascontiguousarray(b, np.float64) for b in blocks]
+        assert [b.size for b in out] == self.block_sizes
+        return out
+
+    def precond_apply(self, cfg, src):
+        src = self._check(src)
+        dst = [np.zeros(n) for n in self.block_sizes]
+        res = _abi.Result()
+        rc = lib().orc_precond_apply(C.byref(self._p), C.byref(cfg), _blocks(src), _blocks(dst), C.byref(res))
+        return rc, dst, res
+
+    def system_apply(self, cfg, src):
+        src = self._check(src)
+        dst = [np.zeros(n) for n in self.block_sizes]
+        rc = lib().orc_system_apply(C.byref(self._p), C.byref(cfg), _blocks(src), _blocks(dst))
+        return rc, dst
+
+    def augment_rhs(self, cfg, rhs):
+        rhs = [b.copy() for b in self._check(rhs)]
+        rc = lib().orc_augment_rhs(C.byref(self._p), C.byref(cfg), _blocks(rhs))
+        return rc, rhs
+
+    def solve(self, cfg, rhs, x0=None, history_cap=4096):
+        rhs = self._check(rhs)
+        x = [np.zeros(n) for n in self.block_sizes] if x0 is None else [b.copy() for b in self._check(x0)]
+        res = _abi.Result()
+        hist = np.zeros(history_cap)
+        cnt = C.c_int32(0)
+        rc = lib().orc_solve(C.byref(self._p), C.byref(cfg), _blocks(rhs), _blocks(x), C.byref(res),
+                             hist.ctypes.data, history_cap, C.byref(cnt))
+        return rc, x, res, hist[:min(cnt.value, history_cap)].copy()
+
+
+def system_from_problem(pb, nranks_emulated=1) -> OracleSystem:
+    """Wrap a problems.SyntheticProblem: W^-1 = 1/M_ii^2, Mp lumped inverse."""
+    mats = {k: pb.mats[k] for k in ("A", "Ct", "C") if k in pb.mats}
+    diags = {_abi.INVW: pb.inv_w_diag_squared()}
+    if "B" in pb.mats:
+        mats.update({k: pb.mats[k] for k in ("B", "Bt", "Mp")})
+        diags[_abi.MP_LUMPED_INV] = pb.mp_lumped_inv()
+    return OracleSystem(mats, diags, pb.block_sizes, nranks_emulated)
