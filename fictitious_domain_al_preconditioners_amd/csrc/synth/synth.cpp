@@ -93,6 +93,19 @@ Csr csr_transpose(const Csr &a) {
   return t;
 }
 
+// rows [r0, r1) of a (column indices unchanged)
+Csr csr_slice_rows(const Csr &a, int64_t r0, int64_t r1) {
+  Csr s;
+  s.nrows = r1 - r0;
+  s.ncols = a.ncols;
+  s.row_ptr.resize(s.nrows + 1);
+  const int64_t k0 = a.row_ptr[r0];
+  for (int64_t r = r0; r <= r1; ++r) s.row_ptr[r - r0] = a.row_ptr[r] - k0;
+  s.col.assign(a.col.begin() + k0, a.col.begin() + a.row_ptr[r1]);
+  s.val.assign(a.val.begin() + k0, a.val.begin() + a.row_ptr[r1]);
+  return s;
+}
+
 // ---------------------------------------------------------------- 1-D pieces
 struct Gauss {
   std::vector<double> x, w;  // on [0,1]
@@ -207,6 +220,9 @@ struct Params {
   int coupling_nq = 3;
   double body_force[3] = {0, 0, 0};
   double embedded_value[3] = {1, 0, 0};
+  // row ranges of this process (multi-GPU row partition); -1 = everything.
+  // u/p ranges are in NODES (z-slabs of the lexicographic numbering), l in dofs.
+  int64_t u_node0 = -1, u_node1 = -1, p_node0 = -1, p_node1 = -1, l0 = -1, l1 = -1;
 };
 
 struct Problem {
@@ -240,16 +256,17 @@ struct Grid {
 
 // Velocity / background block. For ncomp == 1: beta * stiffness. For
 // ncomp == dim: vector Laplace (+ gamma_gd * grad-div).
-void build_A(const Params &P, const Grid &g, Csr &A) {
+void build_A(const Params &P, const Grid &g, Csr &A, int64_t node0, int64_t node1) {
   const int dim = g.dim, nc = P.ncomp;
   const Band1D M = band1d(g.p, g.p, g.N, g.h, 0), K = band1d(g.p, g.p, g.N, g.h, 1),
                G = band1d(g.p, g.p, g.N, g.h, 2);
-  const int64_t nrows = g.nnodes * nc;
-  A.nrows = A.ncols = nrows;
+  const int64_t nrows = (node1 - node0) * nc;
+  A.nrows = nrows;
+  A.ncols = g.nnodes * nc;
   A.row_ptr.assign(nrows + 1, 0);
   // pass 1: counts
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < g.nnodes; ++n) {
+  for (int64_t n = node0; n < node1; ++n) {
     int idx[3] = {0, 0, 0};
     g.split(n, idx);
     int64_t cnt;
@@ -270,7 +287,7 @@ void build_A(const Params &P, const Grid &g, Csr &A) {
             if (!g.boundary(j)) cnt += nc;
           }
     }
-    for (int a = 0; a < nc; ++a) A.row_ptr[n * nc + a + 1] = cnt;
+    for (int a = 0; a < nc; ++a) A.row_ptr[(n - node0) * nc + a + 1] = cnt;
   }
   for (int64_t r = 0; r < nrows; ++r) A.row_ptr[r + 1] += A.row_ptr[r];
   A.col.resize(A.row_ptr[nrows]);
@@ -278,19 +295,19 @@ void build_A(const Params &P, const Grid &g, Csr &A) {
   const double ggd = (P.stokes && P.grad_div) ? P.gamma_grad_div : 0.0;
   // pass 2: fill
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < g.nnodes; ++n) {
+  for (int64_t n = node0; n < node1; ++n) {
     int idx[3] = {0, 0, 0};
     g.split(n, idx);
     if (g.boundary(idx)) {
       for (int a = 0; a < nc; ++a) {
-        const int64_t p0 = A.row_ptr[n * nc + a];
+        const int64_t p0 = A.row_ptr[(n - node0) * nc + a];
         A.col[p0] = (int32_t)(n * nc + a);
         A.val[p0] = 1.0;
       }
       continue;
     }
     int64_t pos[3];
-    for (int a = 0; a < nc; ++a) pos[a] = A.row_ptr[n * nc + a];
+    for (int a = 0; a < nc; ++a) pos[a] = A.row_ptr[(n - node0) * nc + a];
     int j[3] = {0, 0, 0};
     const int f0 = M.first[idx[0]], c0 = M.count[idx[0]];
     const int f1 = M.first[idx[1]], c1 = M.count[idx[1]];
@@ -344,7 +361,8 @@ void build_A(const Params &P, const Grid &g, Csr &A) {
 
 // B = -(div u, q), rows = Q_{p-1} pressure nodes, cols = velocity dofs.
 // Mp = pressure mass (no constraints on pressure).
-void build_B_Mp(const Grid &gu, Csr &B, Csr &Mp, int64_t &n_p) {
+void build_B_Mp(const Grid &gu, Csr &B, Csr &Mp, int64_t &n_p, int64_t pn0, int64_t pn1,
+                bool want_mp) {
   const int dim = gu.dim, pp = gu.p - 1, N = gu.N;
   Grid gp = gu;
   gp.p = pp;
@@ -352,15 +370,20 @@ void build_B_Mp(const Grid &gu, Csr &B, Csr &Mp, int64_t &n_p) {
   gp.nnodes = 1;
   for (int a = 0; a < dim; ++a) gp.nnodes *= gp.n1;
   n_p = gp.nnodes;
+  if (pn0 < 0) {
+    pn0 = 0;
+    pn1 = n_p;
+  }
+  const int64_t nloc = pn1 - pn0;
   const Band1D MX = band1d(pp, gu.p, N, gu.h, 0);  // psi_i phi_j
   // GX[i][j] = int psi_i phi_j'  -> use kind 2 with roles swapped: build
   // (row = Q_p velocity)' x (col = pressure) and read transposed.
   const Band1D GT = band1d(gu.p, pp, N, gu.h, 2);  // GT[j][i] = int phi_j' psi_i
   const Band1D MPP = band1d(pp, pp, N, gu.h, 0);
   // ---- B
-  B.nrows = n_p;
+  B.nrows = nloc;
   B.ncols = gu.nnodes * dim;
-  B.row_ptr.assign(n_p + 1, 0);
+  B.row_ptr.assign(nloc + 1, 0);
   auto for_row = [&](int64_t n, auto &&emit) {
     int idx[3] = {0, 0, 0};
     gp.split(n, idx);
@@ -379,18 +402,18 @@ void build_B_Mp(const Grid &gu, Csr &B, Csr &Mp, int64_t &n_p) {
         }
   };
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < n_p; ++n) {
+  for (int64_t n = 0; n < nloc; ++n) {
     int64_t cnt = 0;
-    for_row(n, [&](const int *, const int *) { cnt += dim; });
+    for_row(n + pn0, [&](const int *, const int *) { cnt += dim; });
     B.row_ptr[n + 1] = cnt;
   }
-  for (int64_t r = 0; r < n_p; ++r) B.row_ptr[r + 1] += B.row_ptr[r];
-  B.col.resize(B.row_ptr[n_p]);
-  B.val.resize(B.row_ptr[n_p]);
+  for (int64_t r = 0; r < nloc; ++r) B.row_ptr[r + 1] += B.row_ptr[r];
+  B.col.resize(B.row_ptr[nloc]);
+  B.val.resize(B.row_ptr[nloc]);
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < n_p; ++n) {
+  for (int64_t n = 0; n < nloc; ++n) {
     int64_t pos = B.row_ptr[n];
-    for_row(n, [&](const int *idx, const int *j) {
+    for_row(n + pn0, [&](const int *idx, const int *j) {
       const int64_t jn = gu.node(j);
       for (int b = 0; b < dim; ++b) {
         double t = 1.0;
@@ -409,23 +432,25 @@ void build_B_Mp(const Grid &gu, Csr &B, Csr &Mp, int64_t &n_p) {
     });
   }
   // ---- Mp
-  Mp.nrows = Mp.ncols = n_p;
-  Mp.row_ptr.assign(n_p + 1, 0);
+  if (!want_mp) return;
+  Mp.nrows = nloc;
+  Mp.ncols = n_p;
+  Mp.row_ptr.assign(nloc + 1, 0);
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < n_p; ++n) {
+  for (int64_t n = 0; n < nloc; ++n) {
     int idx[3] = {0, 0, 0};
-    gp.split(n, idx);
+    gp.split(n + pn0, idx);
     int64_t cnt = 1;
     for (int a = 0; a < dim; ++a) cnt *= MPP.count[idx[a]];
     Mp.row_ptr[n + 1] = cnt;
   }
-  for (int64_t r = 0; r < n_p; ++r) Mp.row_ptr[r + 1] += Mp.row_ptr[r];
-  Mp.col.resize(Mp.row_ptr[n_p]);
-  Mp.val.resize(Mp.row_ptr[n_p]);
+  for (int64_t r = 0; r < nloc; ++r) Mp.row_ptr[r + 1] += Mp.row_ptr[r];
+  Mp.col.resize(Mp.row_ptr[nloc]);
+  Mp.val.resize(Mp.row_ptr[nloc]);
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < n_p; ++n) {
+  for (int64_t n = 0; n < nloc; ++n) {
     int idx[3] = {0, 0, 0};
-    gp.split(n, idx);
+    gp.split(n + pn0, idx);
     int64_t pos = Mp.row_ptr[n];
     int j[3] = {0, 0, 0};
     const int f0 = MPP.first[idx[0]], c0 = MPP.count[idx[0]];
@@ -655,13 +680,24 @@ void build_immersed(const Params &P, const Grid &g, Problem &pb) {
     return e;
   };
   Csr C = expand(Cs, g.nnodes);
-  pb.mats["Ct"] = csr_transpose(C);
-  pb.mats["C"] = std::move(C);
-  pb.mats["M"] = expand(Ms, nl);
-  pb.mats["K"] = expand(Ks, nl);
+  Csr Ct = csr_transpose(C);
+  Csr Mx = expand(Ms, nl), Kx = expand(Ks, nl);
   std::vector<double> gv(nl * nc);
   for (int64_t k = 0; k < nl; ++k)
     for (int b = 0; b < nc; ++b) gv[k * nc + b] = P.embedded_value[b] * gint[k];
+  pb.vecs["n_lambda_global"] = {(double)(nl * nc)};
+  if (P.u_node0 >= 0) {
+    pb.mats["Ct"] = csr_slice_rows(Ct, P.u_node0 * nc, P.u_node1 * nc);
+    pb.mats["C"] = csr_slice_rows(C, P.l0, P.l1);
+    pb.mats["M"] = csr_slice_rows(Mx, P.l0, P.l1);
+    pb.mats["K"] = csr_slice_rows(Kx, P.l0, P.l1);
+    gv = std::vector<double>(gv.begin() + P.l0, gv.begin() + P.l1);
+  } else {
+    pb.mats["Ct"] = std::move(Ct);
+    pb.mats["C"] = std::move(C);
+    pb.mats["M"] = std::move(Mx);
+    pb.mats["K"] = std::move(Kx);
+  }
   pb.vecs["g"] = std::move(gv);
   pb.vecs["immersed_xyz"] = im.xyz;
 }
@@ -672,15 +708,16 @@ void build_rhs(const Params &P, const Grid &g, Problem &pb) {
   std::vector<double> one(g.n1, 0.0);  // (M 1)_i
   for (int i = 0; i < g.n1; ++i)
     for (int k = 0; k < M.count[i]; ++k) one[i] += M.a[(size_t)i * M.W + k];
-  std::vector<double> f(g.nnodes * nc, 0.0);
+  const int64_t n0 = P.u_node0 >= 0 ? P.u_node0 : 0, n1 = P.u_node0 >= 0 ? P.u_node1 : g.nnodes;
+  std::vector<double> f((n1 - n0) * nc, 0.0);
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < g.nnodes; ++n) {
+  for (int64_t n = n0; n < n1; ++n) {
     int idx[3] = {0, 0, 0};
     g.split(n, idx);
     if (g.boundary(idx)) continue;
     double w = one[idx[0]] * one[idx[1]];
     if (dim == 3) w *= one[idx[2]];
-    for (int a = 0; a < nc; ++a) f[n * nc + a] = P.body_force[a] * w;
+    for (int a = 0; a < nc; ++a) f[(n - n0) * nc + a] = P.body_force[a] * w;
   }
   pb.vecs["f"] = std::move(f);
 }
@@ -704,15 +741,44 @@ bool generate(Problem &pb) {
   g.nnodes = 1;
   for (int a = 0; a < g.dim; ++a) g.nnodes *= g.n1;
   if (g.nnodes * P.ncomp > 2147483647LL) return pb.err = "more than 2^31-1 columns", false;
-  build_A(P, g, pb.mats["A"]);
+  const bool part = P.u_node0 >= 0;
+  if (part) {
+    if (P.u_node1 < P.u_node0 || P.u_node1 > g.nnodes || P.l0 < 0 || P.l1 < P.l0)
+      return pb.err = "bad row ranges", false;
+  }
+  build_A(P, g, pb.mats["A"], part ? P.u_node0 : 0, part ? P.u_node1 : g.nnodes);
   if (P.stokes) {
     int64_t n_p = 0;
     Csr B, Mp;
-    build_B_Mp(g, B, Mp, n_p);
-    pb.mats["Bt"] = csr_transpose(B);
+    build_B_Mp(g, B, Mp, n_p, part ? P.p_node0 : -1, part ? P.p_node1 : -1, true);
+    if (part) {
+      // Bt rows of my velocity slab: transpose the B rows of every pressure
+      // node that can couple to it (pressure z-planes touching the slab).
+      const int64_t plane_u = (int64_t)g.n1 * g.n1, np1d = g.N + 1, plane_p = np1d * np1d;
+      const int64_t zu0 = P.u_node0 / plane_u, zu1 = (P.u_node1 + plane_u - 1) / plane_u;  // [zu0, zu1)
+      int64_t zp0 = std::max<int64_t>(0, zu0 / 2 - 1), zp1 = std::min<int64_t>(np1d, (zu1 + 1) / 2 + 1);
+      int64_t stride_p = plane_p;
+      if (g.dim == 2) {  // 2-D: the slabs are grid rows
+        const int64_t yu0 = P.u_node0 / g.n1, yu1 = (P.u_node1 + g.n1 - 1) / g.n1;
+        zp0 = std::max<int64_t>(0, yu0 / 2 - 1);
+        zp1 = std::min<int64_t>(np1d, (yu1 + 1) / 2 + 1);
+        stride_p = np1d;
+      }
+      Csr Bext, dummy;
+      int64_t np_all = 0;
+      build_B_Mp(g, Bext, dummy, np_all, zp0 * stride_p, zp1 * stride_p, false);
+      Csr Bt = csr_transpose(Bext);
+      for (auto &c : Bt.col) c += (int32_t)(zp0 * stride_p);
+      Bt.ncols = np_all;
+      pb.mats["Bt"] = csr_slice_rows(Bt, P.u_node0 * P.ncomp, P.u_node1 * P.ncomp);
+      pb.vecs["rhs_p"] = std::vector<double>(P.p_node1 - P.p_node0, 0.0);
+    } else {
+      pb.mats["Bt"] = csr_transpose(B);
+      pb.vecs["rhs_p"] = std::vector<double>(n_p, 0.0);
+    }
     pb.mats["B"] = std::move(B);
     pb.mats["Mp"] = std::move(Mp);
-    pb.vecs["rhs_p"] = std::vector<double>(n_p, 0.0);
+    pb.vecs["n_p_global"] = {(double)n_p};
   }
   build_immersed(P, g, pb);
   build_rhs(P, g, pb);
@@ -734,6 +800,7 @@ struct alfd_synth_params {
   int32_t immersed_refine, coupling_nq;
   double body_force[3];
   double embedded_value[3];
+  int64_t u_node0, u_node1, p_node0, p_node1, l0, l1;
 };
 
 void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
@@ -757,6 +824,12 @@ void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
   P.radius = sp->radius;
   P.immersed_refine = sp->immersed_refine;
   P.coupling_nq = sp->coupling_nq;
+  P.u_node0 = sp->u_node0;
+  P.u_node1 = sp->u_node1;
+  P.p_node0 = sp->p_node0;
+  P.p_node1 = sp->p_node1;
+  P.l0 = sp->l0;
+  P.l1 = sp->l1;
   if (!generate(*pb)) {
     if (err && errlen > 0) std::snprintf(err, errlen, "%s", pb->err.c_str());
     delete pb;

@@ -30,6 +30,8 @@ class _Params(C.Structure):
         ("center", C.c_double * 3), ("radius", C.c_double),
         ("immersed_refine", C.c_int32), ("coupling_nq", C.c_int32),
         ("body_force", C.c_double * 3), ("embedded_value", C.c_double * 3),
+        ("u_node0", C.c_int64), ("u_node1", C.c_int64), ("p_node0", C.c_int64), ("p_node1", C.c_int64),
+        ("l0", C.c_int64), ("l1", C.c_int64),
     ]
 
 
@@ -90,12 +92,18 @@ class Csr:
                                  self.val.ctypes.data, rp.ctypes.data, col.ctypes.data, val.ctypes.data)
         return Csr(self.ncols, self.nrows, rp, col, val)
 
-    def diagonal(self) -> np.ndarray:
+    def diagonal(self, row_offset: int = 0) -> np.ndarray:
+        """Diagonal of a (row slice of a) square matrix; row r is global row r + row_offset."""
         d = np.zeros(self.nrows)
         rows = np.repeat(np.arange(self.nrows, dtype=np.int64), np.diff(self.row_ptr))
-        mask = rows == self.col
+        mask = (rows + row_offset) == self.col
         d[rows[mask]] = self.val[mask]
         return d
+
+    def slice_rows(self, r0: int, r1: int) -> "Csr":
+        k0, k1 = int(self.row_ptr[r0]), int(self.row_ptr[r1])
+        return Csr(r1 - r0, self.ncols, (self.row_ptr[r0:r1 + 1] - k0).astype(np.int64),
+                   self.col[k0:k1].copy(), self.val[k0:k1].copy())
 
 
 @dataclass
@@ -109,18 +117,28 @@ class SyntheticProblem:
     mats: dict = field(default_factory=dict)
     vecs: dict = field(default_factory=dict)
     _handle: object = None
+    row_ranges: tuple = None   # (u_node0, u_node1, p_node0, p_node1, l0, l1) of this rank, or None
 
     @property
     def block_sizes(self):
+        """LOCAL block sizes (== global when the problem is not partitioned)."""
         n_u = self.mats["A"].nrows
-        n_l = self.mats["Ct"].ncols
+        n_l = self.mats["C"].nrows
         if "B" in self.mats:
             return [n_u, self.mats["B"].nrows, n_l]
         return [n_u, n_l]
 
+    @property
+    def global_sizes(self):
+        n_u = self.mats["A"].ncols
+        n_l = self.mats["Ct"].ncols
+        if "B" in self.mats:
+            return [n_u, self.mats["B"].ncols and self.mats["Mp"].ncols, n_l]
+        return [n_u, n_l]
+
     def inv_w_diag_squared(self) -> np.ndarray:
         """W^-1 = 1 / M_ii^2 (stokes_immersed_boundary.cc:976-978, immersed_laplace.cc:866-869)."""
-        d = self.mats["M"].diagonal()
+        d = self.mats["M"].diagonal(self.row_ranges[4] if self.row_ranges else 0)
         return 1.0 / (d * d)
 
     def mp_lumped_inv(self) -> np.ndarray:
@@ -137,7 +155,11 @@ class SyntheticProblem:
 
 def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False, grad_div=False,
              gamma_grad_div=0.0, beta=1.0, center=(0.5, 0.5, 0.5), radius=0.2, immersed_refine=3,
-             coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0)) -> SyntheticProblem:
+             coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0),
+             row_ranges=None) -> SyntheticProblem:
+    """row_ranges = (u_node0, u_node1, p_node0, p_node1, l0, l1): generate only this
+    rank's rows (node ranges for the background spaces, dof range for the
+    multiplier); column indices stay global.  None = the whole problem."""
     lib = _load()
     p = _Params()
     p.dim, p.degree, p.ncomp, p.n_cells = dim, degree, ncomp, n_cells
@@ -149,6 +171,8 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
         p.body_force[i] = body_force[i] if i < len(body_force) else 0.0
         p.embedded_value[i] = embedded_value[i] if i < len(embedded_value) else 0.0
     p.radius, p.immersed_refine, p.coupling_nq = radius, immersed_refine, coupling_nq
+    rr = tuple(int(v) for v in row_ranges) if row_ranges is not None else (-1,) * 6
+    p.u_node0, p.u_node1, p.p_node0, p.p_node1, p.l0, p.l1 = rr
     err = C.create_string_buffer(256)
     h = lib.alfd_synth_generate(C.byref(p), err, 256)
     if not h:
@@ -156,24 +180,26 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     params = dict(dim=dim, degree=degree, ncomp=ncomp, n_cells=n_cells, lo=lo, hi=hi, stokes=stokes,
                   grad_div=grad_div, gamma_grad_div=gamma_grad_div, beta=beta, center=tuple(center),
                   radius=radius, immersed_refine=immersed_refine, coupling_nq=coupling_nq)
-    pb = SyntheticProblem(params=params, _handle=C.c_void_p(h))
+    pb = SyntheticProblem(params=params, _handle=C.c_void_p(h),
+                          row_ranges=rr if row_ranges is not None else None)
     for name in ("A", "B", "Bt", "Mp", "Ct", "C", "M", "K"):
         nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
         rp, col, val = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
         if lib.alfd_synth_matrix(pb._handle, name.encode(), C.byref(nr), C.byref(nc), C.byref(nnz),
                                  C.byref(rp), C.byref(col), C.byref(val)) != 0:
             continue
-        n = max(nnz.value, 1)
-        pb.mats[name] = Csr(
-            nr.value, nc.value,
-            np.ctypeslib.as_array(rp, shape=(nr.value + 1,)),
-            np.ctypeslib.as_array(col, shape=(n,))[:nnz.value],
-            np.ctypeslib.as_array(val, shape=(n,))[:nnz.value])
+        if nnz.value > 0:
+            cols = np.ctypeslib.as_array(col, shape=(nnz.value,))
+            vals = np.ctypeslib.as_array(val, shape=(nnz.value,))
+        else:
+            cols, vals = np.zeros(0, np.int32), np.zeros(0, np.float64)
+        pb.mats[name] = Csr(nr.value, nc.value, np.ctypeslib.as_array(rp, shape=(nr.value + 1,)), cols, vals)
     for name in ("f", "g", "rhs_p", "immersed_xyz"):
         n, data = C.c_int64(), C.POINTER(C.c_double)()
         if lib.alfd_synth_vector(pb._handle, name.encode(), C.byref(n), C.byref(data)) != 0:
             continue
-        pb.vecs[name] = np.ctypeslib.as_array(data, shape=(max(n.value, 1),))[:n.value]
+        pb.vecs[name] = (np.ctypeslib.as_array(data, shape=(n.value,)) if n.value > 0
+                         else np.zeros(0, np.float64))
     return pb
 
 
@@ -194,7 +220,8 @@ def laplace3d_sphere(n_cells=128, immersed_refine=5, coupling_nq=3) -> Synthetic
                     body_force=(0.0,), embedded_value=(1.0,))
 
 
-def stokes3d_sphere(n_cells=64, immersed_refine=4, gamma_grad_div=10.0, coupling_nq=4) -> SyntheticProblem:
+def stokes3d_sphere(n_cells=64, immersed_refine=4, gamma_grad_div=10.0, coupling_nq=4,
+                    row_ranges=None) -> SyntheticProblem:
     """cfg 4 (north star): stokes_immersed_boundary + parameters_stokes_3d.prm.
     Taylor-Hood Q2/Q1 on n^3 cells, grad-div on (prm:21), sphere R = 0.1 centre
     (.5,.5,.5) (stokes_immersed_boundary.cc:427), body force (1,0,0) (prm:52),
@@ -202,7 +229,7 @@ def stokes3d_sphere(n_cells=64, immersed_refine=4, gamma_grad_div=10.0, coupling
     return generate(dim=3, degree=2, ncomp=3, n_cells=n_cells, stokes=True, grad_div=True,
                     gamma_grad_div=gamma_grad_div, center=(0.5, 0.5, 0.5), radius=0.1,
                     immersed_refine=immersed_refine, coupling_nq=coupling_nq,
-                    body_force=(1.0, 0.0, 0.0), embedded_value=(-1.0, 1.0, 0.0))
+                    body_force=(1.0, 0.0, 0.0), embedded_value=(-1.0, 1.0, 0.0), row_ranges=row_ranges)
 
 
 def stokes2d_circle(n_cells=32, immersed_refine=4, gamma_grad_div=10.0, coupling_nq=3) -> SyntheticProblem:

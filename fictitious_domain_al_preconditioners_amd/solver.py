@@ -254,10 +254,10 @@ class Context:
         return {k: dict(ms=float(ms[i]), launches=int(n[i]), bytes=float(b[i])) for i, k in enumerate(names)}
 
 
-def context_from_problem(pb, cfg: _abi.Config, device_id=0) -> Context:
-    """Upload a problems.SyntheticProblem with the reference's diagonal choices:
-    W^-1 = 1/M_ii^2 (stokes...:976-978), lumped pressure mass (stokes...:946-954)."""
-    ctx = Context(device_id)
+def upload_problem(ctx: Context, pb, cfg: _abi.Config) -> Context:
+    """Upload a problems.SyntheticProblem (whole, or this rank's rows) with the
+    reference's diagonal choices: W^-1 = 1/M_ii^2 (stokes...:976-978), lumped
+    pressure mass (stokes...:946-954)."""
     ctx.set_matrix(_abi.A, pb.mats["A"])
     ctx.set_matrix(_abi.CT, pb.mats["Ct"])
     ctx.set_matrix(_abi.C_, pb.mats["C"])
@@ -270,6 +270,10 @@ def context_from_problem(pb, cfg: _abi.Config, device_id=0) -> Context:
     ctx.configure(cfg)
     ctx.setup(pb.block_sizes)
     return ctx
+
+
+def context_from_problem(pb, cfg: _abi.Config, device_id=0) -> Context:
+    return upload_problem(Context(device_id), pb, cfg)
 
 
 # ---------------------------------------------------------------------------

@@ -82,9 +82,18 @@ inline void choose_lanes(Csr &m) {
     m.L = 4;
 }
 
+// 0 = canonical lane order (parity); 1 = plain sequential row sums, the order
+// dealii::SparseMatrix::vmult uses -- ONLY for timing the cpu_baseline.
+static int g_row_order = 0;
+
 inline double row_sum(const Csr &m, int64_t r, const double *x) {
   double lane[64];
   const int64_t k0 = m.rp[r], k1 = m.rp[r + 1];
+  if (g_row_order == 1) {
+    double s = 0.0;
+    for (int64_t k = k0; k < k1; ++k) s += m.val[k] * x[m.col[k]];
+    return s;
+  }
   const int L = m.L, V = m.V;
   for (int l = 0; l < L; ++l) {
     double acc = 0.0;
@@ -753,6 +762,11 @@ int orc_set_threads(int n) {
   (void)n;
   return 1;
 #endif
+}
+
+int orc_set_row_order(int order) {
+  orc::g_row_order = order == 1 ? 1 : 0;
+  return orc::g_row_order;
 }
 
 // Scalar known-answer hook for a6: evaluates res0 + sum_i res_i / (x - p_i)

@@ -56,6 +56,8 @@ def lib():
                                 C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         l.orc_set_threads.restype = C.c_int
         l.orc_set_threads.argtypes = [C.c_int]
+        l.orc_set_row_order.restype = C.c_int
+        l.orc_set_row_order.argtypes = [C.c_int]
         l.orc_rational_eval.restype = C.c_double
         l.orc_rational_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double]
         _lib = l
@@ -65,6 +67,11 @@ def lib():
 def set_threads(n: int) -> int:
     """Set the oracle's OpenMP thread count; returns the count in effect."""
     return lib().orc_set_threads(int(n))
+
+
+def set_row_order(order: int) -> int:
+    """0 = canonical (parity); 1 = sequential row sums (cpu_baseline timing only)."""
+    return lib().orc_set_row_order(int(order))
 
 
 def _csr_struct(m) -> _Csr:
