@@ -22,9 +22,12 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <climits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "alfd/alfd.h"
@@ -66,6 +69,12 @@ struct DevCsr {
   int32_t *send_idx = nullptr;              // local indices to pack
   double *send_buf = nullptr, *halo = nullptr;
   int64_t n_halo = 0;
+  // LDS-window format (long-row matrices): see spmv_window_kernel
+  bool win = false;
+  int32_t win_RB = 0, win_maxW = 0;
+  int64_t win_nblocks = 0, win_fallback_blocks = 0, win_nseg = 0;
+  uint16_t *lcol = nullptr;
+  int32_t *blk_seg_begin = nullptr, *blk_W = nullptr, *seg_col = nullptr, *seg_off = nullptr;
   double algorithmic_bytes() const {
     // nnz*(8+4) + (nrows+1)*8 + nrows*8 + ncols*8  (x read once)
     return (double)nnz * 12.0 + (double)(n_list + 1) * 8.0 + (double)n_list * 8.0 +
@@ -144,6 +153,8 @@ struct alfd_ctx {
   int64_t t_launches[ALFD_T_NCLASSES] = {0, 0, 0, 0};
   double t_bytes[ALFD_T_NCLASSES] = {0, 0, 0, 0};
   std::vector<void *> allocs;
+  int spmv_stream_R = 2, spmv_stream_U = 8, spmv_nt = 0, spmv_grid_mult = 8;  // tunables (env ALFD_SPMV_*)
+  int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8;
   int64_t ntot() const { return off[nblocks]; }
 };
 
@@ -225,6 +236,58 @@ static void launch_spmv_L(alfd_ctx *ctx, const DevCsr &m, const double *x, doubl
 #undef ALFD_SPMV
 }
 
+template <int R, int U, bool NT>
+static void launch_stream(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
+                          const double *d, double *y2) {
+  const int64_t nbatches = (m.nrows + R - 1) / R;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nbatches + 3) / 4, 256 * ctx->spmv_grid_mult));
+#define ALFD_STREAM(EPI)                                                                              \
+  hipLaunchKernelGGL((spmv_stream_kernel<R, U, EPI, NT>), dim3(grid), dim3(kBlock), 0, ctx->stream,   \
+                     m.nrows, m.rp, m.col, m.val, x, m.halo, m.n_local_cols, y, alpha, d, y2)
+  if (epi == 0) ALFD_STREAM(0);
+  else if (epi == 1) ALFD_STREAM(1);
+  else if (epi == 2) ALFD_STREAM(2);
+  else ALFD_STREAM(3);
+#undef ALFD_STREAM
+}
+
+template <bool NT>
+static bool launch_stream_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi,
+                             double alpha, const double *d, double *y2) {
+  const int R = ctx->spmv_stream_R, U = ctx->spmv_stream_U;
+#define ALFD_RU(RR, UU) \
+  if (R == RR && U == UU) return launch_stream<RR, UU, NT>(ctx, m, x, y, epi, alpha, d, y2), true
+  ALFD_RU(2, 2); ALFD_RU(2, 4); ALFD_RU(4, 2); ALFD_RU(4, 4); ALFD_RU(4, 8); ALFD_RU(8, 4); ALFD_RU(8, 8);
+  ALFD_RU(1, 4); ALFD_RU(2, 8); ALFD_RU(8, 2);
+#undef ALFD_RU
+  return false;
+}
+
+template <int R, int U>
+static void launch_window(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
+                          const double *d, double *y2) {
+  const size_t lds = (size_t)m.win_maxW * sizeof(double);
+#define ALFD_WIN(EPI)                                                                                  \
+  hipLaunchKernelGGL((spmv_window_kernel<R, U, EPI>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds, \
+                     ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin,      \
+                     m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2)
+  if (epi == 0) ALFD_WIN(0);
+  else if (epi == 1) ALFD_WIN(1);
+  else if (epi == 2) ALFD_WIN(2);
+  else ALFD_WIN(3);
+#undef ALFD_WIN
+}
+
+static bool launch_window_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi,
+                             double alpha, const double *d, double *y2) {
+  const int R = ctx->spmv_stream_R, U = ctx->spmv_stream_U;
+#define ALFD_RU(RR, UU) \
+  if (R == RR && U == UU) return launch_window<RR, UU>(ctx, m, x, y, epi, alpha, d, y2), true
+  ALFD_RU(1, 4); ALFD_RU(2, 4); ALFD_RU(2, 8); ALFD_RU(4, 2); ALFD_RU(4, 4); ALFD_RU(4, 8); ALFD_RU(8, 4);
+#undef ALFD_RU
+  return false;
+}
+
 static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x);
 
 // epi 0: y = A x; 1: y = fma(alpha, A x, y); 2: y = d .* (A x); 3: y = A x, y2 = d .* y
@@ -240,6 +303,18 @@ static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, do
   }
   if (m.n_list == 0) return ALFD_OK;
   Timer tm(ctx, slot == ALFD_A ? ALFD_T_SPMV_A : ALFD_T_SPMV_OTHER, m.algorithmic_bytes());
+  if (m.win && launch_window_RU(ctx, m, x, y, epi, alpha, d, y2)) {
+    HIPC(hipGetLastError());
+    return ALFD_OK;
+  }
+  if (m.L == 64 && !m.sparse && ctx->spmv_stream_R > 0) {
+    const bool ok = ctx->spmv_nt ? launch_stream_RU<true>(ctx, m, x, y, epi, alpha, d, y2)
+                                 : launch_stream_RU<false>(ctx, m, x, y, epi, alpha, d, y2);
+    if (ok) {
+      HIPC(hipGetLastError());
+      return ALFD_OK;
+    }
+  }
   switch (m.L) {
     case 4: launch_spmv_L<4>(ctx, m, x, y, epi, alpha, d, y2); break;
     case 8: launch_spmv_L<8>(ctx, m, x, y, epi, alpha, d, y2); break;
@@ -631,6 +706,107 @@ static void choose_lanes(DevCsr &m, int64_t nonempty) {
   else m.L = 4;
 }
 
+// Build the LDS-window format of a long-row matrix (host, multi-threaded).
+// col: column indices in the LOCAL index space [local | halo].
+static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col) {
+  const int RB = ctx->win_RB, maxW = ctx->win_maxW, GAP = ctx->win_gap;
+  const int64_t nb = (m.nrows + RB - 1) / RB;
+  if (nb == 0 || nb > 2147483000LL) return ALFD_OK;
+  std::vector<uint16_t> lcol(m.nnz);
+  std::vector<int32_t> blkW(nb), blk_nseg(nb);
+  const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::vector<int32_t>> t_seg_col(T), t_seg_off(T);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() {
+      const int64_t b0 = nb * t / T, b1 = nb * (t + 1) / T;
+      std::vector<uint8_t> mark;
+      std::vector<int32_t> pos;
+      for (int64_t b = b0; b < b1; ++b) {
+        const int64_t r0 = b * RB, r1 = std::min<int64_t>(r0 + RB, m.nrows);
+        const int64_t k0 = rp[r0], k1 = rp[r1];
+        blkW[b] = 0;
+        blk_nseg[b] = 0;
+        if (k1 == k0) continue;
+        int32_t clo = INT32_MAX, chi = -1;
+        for (int64_t k = k0; k < k1; ++k) {
+          clo = std::min(clo, col[k]);
+          chi = std::max(chi, col[k]);
+        }
+        const int64_t range = (int64_t)chi - clo + 1;
+        if (range > (int64_t)(1 << 22)) {
+          blkW[b] = -1;
+          continue;
+        }
+        mark.assign(range, 0);
+        for (int64_t k = k0; k < k1; ++k) mark[col[k] - clo] = 1;
+        pos.assign(range, -1);
+        int32_t W = 0, nseg = 0;
+        const size_t seg_base = t_seg_col[t].size();
+        int64_t c = 0;
+        while (c < range) {
+          if (!mark[c]) {
+            ++c;
+            continue;
+          }
+          // segment starts at c; extend over gaps shorter than GAP
+          int64_t e = c, last = c;
+          while (e < range) {
+            if (mark[e]) last = e;
+            else if (e - last >= GAP) break;
+            ++e;
+          }
+          t_seg_col[t].push_back((int32_t)(clo + c));
+          t_seg_off[t].push_back(W);
+          for (int64_t q = c; q <= last; ++q) pos[q] = W++;
+          ++nseg;
+          c = last + 1;
+        }
+        if (W > maxW || W > 65535) {
+          t_seg_col[t].resize(seg_base);
+          t_seg_off[t].resize(seg_base);
+          blkW[b] = -1;
+          continue;
+        }
+        blkW[b] = W;
+        blk_nseg[b] = nseg;
+        for (int64_t k = k0; k < k1; ++k) lcol[k] = (uint16_t)pos[col[k] - clo];
+      }
+    });
+  for (auto &x : th) x.join();
+  std::vector<int32_t> seg_begin(nb + 1, 0), seg_col, seg_off;
+  for (int64_t b = 0; b < nb; ++b) seg_begin[b + 1] = seg_begin[b] + blk_nseg[b];
+  for (int t = 0; t < T; ++t) {
+    seg_col.insert(seg_col.end(), t_seg_col[t].begin(), t_seg_col[t].end());
+    seg_off.insert(seg_off.end(), t_seg_off[t].begin(), t_seg_off[t].end());
+  }
+  int32_t mw = 0;
+  int64_t fb = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    mw = std::max(mw, blkW[b]);
+    fb += blkW[b] < 0;
+  }
+  if (fb * 2 > nb) return ALFD_OK;  // windows do not pay for this matrix: keep the plain kernels
+  m.win_RB = RB;
+  m.win_maxW = std::max(mw, 1);
+  m.win_nblocks = nb;
+  m.win_fallback_blocks = fb;
+  m.win_nseg = (int64_t)seg_col.size();
+  RC(dev_alloc(ctx, &m.lcol, m.nnz));
+  RC(dev_alloc(ctx, &m.blk_seg_begin, nb + 1));
+  RC(dev_alloc(ctx, &m.blk_W, nb));
+  RC(dev_alloc(ctx, &m.seg_col, m.win_nseg));
+  RC(dev_alloc(ctx, &m.seg_off, m.win_nseg));
+  HIPC(hipMemcpyAsync(m.lcol, lcol.data(), m.nnz * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(m.blk_seg_begin, seg_begin.data(), (nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(m.blk_W, blkW.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(m.seg_col, seg_col.data(), m.win_nseg * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(m.seg_off, seg_off.data(), m.win_nseg * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  m.win = true;
+  return ALFD_OK;
+}
+
 static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, const int64_t *rp,
                          const int32_t *col, const double *val) {
   DevCsr &m = ctx->mat[slot];
@@ -742,6 +918,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     HIPC(hipMemcpyAsync(m.rp, rp, (nrows + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
   }
   HIPC(hipStreamSynchronize(ctx->stream));
+  if (ctx->win_enable && m.L == 64 && !m.sparse && m.nnz > 0) RC(build_window(ctx, m, rp, col_up));
   m.present = true;
   return ALFD_OK;
 }
@@ -952,6 +1129,14 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
     return ALFD_E_HIP;
   }
   alfd_default_config(&ctx->cfg, ALFD_AL_STOKES);
+  if (const char *e = std::getenv("ALFD_SPMV_STREAM_R")) ctx->spmv_stream_R = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_STREAM_U")) ctx->spmv_stream_U = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_NT")) ctx->spmv_nt = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_GRID")) ctx->spmv_grid_mult = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("ALFD_SPMV_WINDOW")) ctx->win_enable = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB")) ctx->win_RB = std::max(4, std::atoi(e));
+  if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
+  if (const char *e = std::getenv("ALFD_SPMV_WINDOW_GAP")) ctx->win_gap = std::max(1, std::atoi(e));
   *out = ctx;
   return ALFD_OK;
 }

@@ -94,6 +94,216 @@ __global__ __launch_bounds__(kBlock) void spmv_kernel(int64_t nrows, const int64
 }
 
 // --------------------------------------------------------------------------
+// Streaming CSR SpMV for long rows (canonical L = 64).  One wave owns a batch
+// of R consecutive rows and streams their CONTIGUOUS nnz range with perfectly
+// coalesced, U-way unrolled col/val loads: U*768 B (+ the x gathers) in flight
+// per wave instead of one row's worth, and no idle lanes at row tails.
+// Bit-compatible with the canonical order: entry k of row i belongs to
+// canonical lane (k - k0_i) mod 64; the stream lane that sees it is
+// (k - k_begin) mod 64 and stays the same for all later entries of that
+// canonical lane (k advances by 64), so each stream lane's per-row accumulator
+// IS one canonical lane partial, rotated by d_i = (k0_i - k_begin) mod 64.  One
+// ds_bpermute un-rotates before the butterfly.
+template <int R, int U, int EPI, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
+    int64_t nrows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+    const double *__restrict__ val, const double *__restrict__ x, const double *__restrict__ x_halo,
+    int32_t n_local, double *__restrict__ y, double alpha, const double *__restrict__ d,
+    double *__restrict__ y2) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nbatches = (nrows + R - 1) / R;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < nbatches; b += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = b * R;
+    int64_t kb[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) kb[i] = rp[r0 + i < nrows ? r0 + i : nrows];  // wave-uniform
+    const int64_t k_begin = kb[0];
+    const int32_t n_batch = (int32_t)(kb[R] - k_begin);
+    int32_t rel[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) rel[i] = (int32_t)(kb[i] - k_begin);
+    double acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.0;
+    const int32_t *cb = col + k_begin;
+    const double *vb = val + k_begin;
+    for (int32_t base = 0; base < n_batch; base += 64 * U) {
+      int32_t c[U];
+      double v[U], xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t o = base + 64 * u + lane;
+        if (o < n_batch) {
+          c[u] = NT ? __builtin_nontemporal_load(cb + o) : cb[o];
+          v[u] = NT ? __builtin_nontemporal_load(vb + o) : vb[o];
+        } else {
+          c[u] = -1;
+          v[u] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xv[u] = 0.0;
+        if (c[u] >= 0) xv[u] = (c[u] < n_local) ? x[c[u]] : x_halo[c[u] - n_local];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t o = base + 64 * u + lane;
+        if (c[u] >= 0) {
+#pragma unroll
+          for (int i = 0; i < R; ++i)
+            if (o >= rel[i] && o < rel[i + 1]) acc[i] = fma(v[u], xv[u], acc[i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      if (r < nrows) {  // wave-uniform
+        const int dsh = rel[i] & 63;
+        double s = __shfl(acc[i], (lane + dsh) & 63, 64);
+        s = group_reduce<64>(s);
+        if (lane == 0) {
+          if (EPI == 0)
+            y[r] = s;
+          else if (EPI == 1)
+            y[r] = fma(alpha, s, y[r]);
+          else if (EPI == 2)
+            y[r] = d[r] * s;
+          else {
+            y[r] = s;
+            y2[r] = d[r] * s;
+          }
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// LDS-windowed streaming SpMV (the roofline kernel for long-row matrices).
+// Rows are grouped in blocks of RB; at upload the host finds, per block, the
+// union of column intervals its rows touch (the "x window"), lays the
+// intervals out back to back and rewrites every column index as a 16-bit
+// offset into that window.  A workgroup then
+//   1. stages its window from x into LDS with coalesced loads (each x entry is
+//      fetched once per block instead of once per use),
+//   2. streams val (8 B) + local col (2 B) = 10 B/nnz instead of 12 B/nnz,
+//   3. gathers from LDS.
+// Same fma/tree order as spmv_stream_kernel => bit-identical results.
+// Blocks whose window exceeds the LDS budget (blk_W < 0) gather from global
+// memory with the original 32-bit columns.
+template <int R, int U, int EPI>
+__global__ __launch_bounds__(kBlock) void spmv_window_kernel(
+    int64_t nrows, int32_t RB, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+    const uint16_t *__restrict__ lcol, const double *__restrict__ val,
+    const int32_t *__restrict__ blk_seg_begin, const int32_t *__restrict__ blk_W,
+    const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
+    const double *__restrict__ x, const double *__restrict__ x_halo, int32_t n_local,
+    double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2) {
+  extern __shared__ double xs[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t b = blockIdx.x;
+  const int32_t W = blk_W[b];
+  if (W >= 0) {
+    const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
+    for (int32_t s = s0 + wave; s < s1; s += 4) {
+      const int32_t c0 = seg_col[s], o0 = seg_off[s];
+      const int32_t len = ((s + 1 < s1) ? seg_off[s + 1] : W) - o0;
+      for (int32_t i = lane; i < len; i += 64) {
+        const int32_t c = c0 + i;
+        xs[o0 + i] = (c < n_local) ? x[c] : x_halo[c - n_local];
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t row_begin = b * RB;
+  const int64_t row_end = (row_begin + RB < nrows) ? row_begin + RB : nrows;
+  for (int64_t r0 = row_begin + (int64_t)wave * R; r0 < row_end; r0 += 4 * R) {
+    int64_t kb[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) kb[i] = rp[r0 + i < row_end ? r0 + i : row_end];  // wave-uniform
+    const int64_t k_begin = kb[0];
+    const int32_t n_batch = (int32_t)(kb[R] - k_begin);
+    int32_t rel[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) rel[i] = (int32_t)(kb[i] - k_begin);
+    double acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.0;
+    const double *vb = val + k_begin;
+    if (W >= 0) {
+      const uint16_t *cb = lcol + k_begin;
+      for (int32_t base = 0; base < n_batch; base += 64 * U) {
+        int32_t c[U];
+        double v[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t o = base + 64 * u + lane;
+          if (o < n_batch) {
+            c[u] = cb[o];
+            v[u] = vb[o];
+          } else {
+            c[u] = -1;
+            v[u] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = c[u] >= 0 ? xs[c[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t o = base + 64 * u + lane;
+          if (c[u] >= 0) {
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+              if (o >= rel[i] && o < rel[i + 1]) acc[i] = fma(v[u], xv[u], acc[i]);
+          }
+        }
+      }
+    } else {
+      const int32_t *cb = col + k_begin;
+      for (int32_t base = 0; base < n_batch; base += 64 * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t o = base + 64 * u + lane;
+          if (o < n_batch) {
+            const int32_t c = cb[o];
+            const double xv = (c < n_local) ? x[c] : x_halo[c - n_local];
+            const double v = vb[o];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+              if (o >= rel[i] && o < rel[i + 1]) acc[i] = fma(v, xv, acc[i]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      if (r < row_end) {  // wave-uniform
+        const int dsh = rel[i] & 63;
+        double s = __shfl(acc[i], (lane + dsh) & 63, 64);
+        s = group_reduce<64>(s);
+        if (lane == 0) {
+          if (EPI == 0)
+            y[r] = s;
+          else if (EPI == 1)
+            y[r] = fma(alpha, s, y[r]);
+          else if (EPI == 2)
+            y[r] = d[r] * s;
+          else {
+            y[r] = s;
+            y2[r] = d[r] * s;
+          }
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // Streaming vector kernels. All vectors are padded to a multiple of kChunk with
 // zeros, so no bounds checks: one workgroup per chunk, thread t owns the pairs
 // base + e*512 + 2t -- the SAME mapping as the canonical dot, which lets the
