@@ -706,6 +706,37 @@ static void choose_lanes(DevCsr &m, int64_t nonempty) {
   else m.L = 4;
 }
 
+// Host-only part of the halo plan of one row-partitioned matrix (no HIP, no
+// communication): off-rank columns sorted unique (ascending global index =>
+// grouped by owner), columns rewritten to the local index space
+// [owned | halo], and the receive counts per owner.  Exposed through the ABI
+// as alfd_host_halo_plan so it can be exercised without a GPU.
+static void host_halo_plan(int64_t nnz, const int32_t *col, const int64_t *col_offsets, int nranks, int rank,
+                           int32_t *col_local, std::vector<int32_t> &halo_globals, int64_t *recv_off) {
+  const int64_t c0 = col_offsets[rank], c1 = col_offsets[rank + 1];
+  halo_globals.clear();
+  for (int64_t k = 0; k < nnz; ++k)
+    if (col[k] < c0 || col[k] >= c1) halo_globals.push_back(col[k]);
+  std::sort(halo_globals.begin(), halo_globals.end());
+  halo_globals.erase(std::unique(halo_globals.begin(), halo_globals.end()), halo_globals.end());
+  const int32_t n_local = (int32_t)(c1 - c0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int32_t c = col[k];
+    if (c >= c0 && c < c1)
+      col_local[k] = (int32_t)(c - c0);
+    else
+      col_local[k] = n_local + (int32_t)(std::lower_bound(halo_globals.begin(), halo_globals.end(), c) -
+                                         halo_globals.begin());
+  }
+  for (int p = 0; p <= nranks; ++p) recv_off[p] = 0;
+  for (int32_t c : halo_globals) {
+    const int owner =
+        (int)(std::upper_bound(col_offsets, col_offsets + nranks + 1, (int64_t)c) - col_offsets) - 1;
+    recv_off[owner + 1]++;
+  }
+  for (int p = 0; p < nranks; ++p) recv_off[p + 1] += recv_off[p];
+}
+
 // Build the LDS-window format of a long-row matrix (host, multi-threaded).
 // col: column indices in the LOCAL index space [local | halo].
 static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col) {
@@ -828,30 +859,12 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     const std::vector<int64_t> &po = ctx->part[cb];
     const int64_t c0 = po[ctx->rank], c1 = po[ctx->rank + 1];
     m.n_local_cols = (int32_t)(c1 - c0);
-    // off-rank columns, sorted unique (ascending global => grouped by owner)
     std::vector<int32_t> hal;
-    for (int64_t k = 0; k < m.nnz; ++k)
-      if (col[k] < c0 || col[k] >= c1) hal.push_back(col[k]);
-    std::sort(hal.begin(), hal.end());
-    hal.erase(std::unique(hal.begin(), hal.end()), hal.end());
-    m.n_halo = (int64_t)hal.size();
     remap.resize(m.nnz);
-    for (int64_t k = 0; k < m.nnz; ++k) {
-      const int32_t c = col[k];
-      if (c >= c0 && c < c1)
-        remap[k] = (int32_t)(c - c0);
-      else
-        remap[k] = m.n_local_cols + (int32_t)(std::lower_bound(hal.begin(), hal.end(), c) - hal.begin());
-    }
-    col_up = remap.data();
-    // receive plan: halo entries grouped by owner; send plan obtained by
-    // exchanging the requested global ids (host side, via RCCL on int32).
     m.recv_off.assign(ctx->nranks + 1, 0);
-    for (int32_t c : hal) {
-      const int owner = (int)(std::upper_bound(po.begin(), po.end(), (int64_t)c) - po.begin()) - 1;
-      m.recv_off[owner + 1]++;
-    }
-    for (int p = 0; p < ctx->nranks; ++p) m.recv_off[p + 1] += m.recv_off[p];
+    host_halo_plan(m.nnz, col, po.data(), ctx->nranks, ctx->rank, remap.data(), hal, m.recv_off.data());
+    m.n_halo = (int64_t)hal.size();
+    col_up = remap.data();
     // counts all-to-all through an all-gather of the nranks x nranks matrix
     std::vector<int32_t> cnt_local(ctx->nranks), cnt_all((size_t)ctx->nranks * ctx->nranks);
     for (int p = 0; p < ctx->nranks; ++p) cnt_local[p] = (int32_t)(m.recv_off[p + 1] - m.recv_off[p]);
@@ -918,7 +931,10 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     HIPC(hipMemcpyAsync(m.rp, rp, (nrows + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
   }
   HIPC(hipStreamSynchronize(ctx->stream));
-  if (ctx->win_enable && m.L == 64 && !m.sparse && m.nnz > 0) RC(build_window(ctx, m, rp, col_up));
+  // the windowed kernel launches one workgroup per row block: only for matrices with
+  // enough row blocks to fill the chip (256 CUs x several workgroups)
+  if (ctx->win_enable && m.L == 64 && !m.sparse && m.nnz > 0 && m.nrows >= (int64_t)ctx->win_RB * 2048)
+    RC(build_window(ctx, m, rp, col_up));
   m.present = true;
   return ALFD_OK;
 }
@@ -1404,6 +1420,22 @@ int alfd_dot(alfd_ctx_t ctx, int64_t n, const double *x, const double *y, double
   hipFree(dy);
   hipFree(part);
   hipFree(sc);
+  return ALFD_OK;
+}
+
+int alfd_host_halo_plan(int64_t nnz, const int32_t *col, const int64_t *col_offsets, int nranks, int rank,
+                        int32_t *col_local, int32_t *halo_globals, int64_t halo_capacity, int64_t *n_halo,
+                        int64_t *recv_off) {
+  if (nnz < 0 || nranks < 1 || rank < 0 || rank >= nranks || !col_offsets || !col_local || !n_halo || !recv_off ||
+      (nnz > 0 && !col))
+    return ALFD_E_INVALID;
+  std::vector<int32_t> hal;
+  host_halo_plan(nnz, col, col_offsets, nranks, rank, col_local, hal, recv_off);
+  *n_halo = (int64_t)hal.size();
+  if (halo_globals) {
+    if ((int64_t)hal.size() > halo_capacity) return ALFD_E_INVALID;
+    std::copy(hal.begin(), hal.end(), halo_globals);
+  }
   return ALFD_OK;
 }
 

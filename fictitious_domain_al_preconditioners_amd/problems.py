@@ -59,6 +59,27 @@ def _load():
     return _lib
 
 
+class _NativeHandle:
+    """Owns one generator result; freed when the last array viewing it dies."""
+
+    def __init__(self, ptr):
+        self.ptr = C.c_void_p(ptr)
+
+    def __del__(self):
+        if self.ptr and _lib is not None:
+            _lib.alfd_synth_free(self.ptr)
+            self.ptr = None
+
+
+def _view(ptr, n, ctype, dtype, owner):
+    """Zero-copy numpy view of native memory that keeps `owner` alive."""
+    if n <= 0:
+        return np.zeros(0, dtype)
+    buf = (ctype * n).from_address(C.addressof(ptr.contents))
+    buf._owner = owner
+    return np.frombuffer(buf, dtype=dtype)
+
+
 @dataclass
 class Csr:
     """Host CSR block: int64 row_ptr, int32 col (ascending per row), fp64 val."""
@@ -147,12 +168,6 @@ class SyntheticProblem:
         s = np.add.reduceat(mp.val, mp.row_ptr[:-1])
         return 1.0 / s
 
-    def __del__(self):
-        if self._handle is not None and _lib is not None:
-            _lib.alfd_synth_free(self._handle)
-            self._handle = None
-
-
 def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False, grad_div=False,
              gamma_grad_div=0.0, beta=1.0, center=(0.5, 0.5, 0.5), radius=0.2, immersed_refine=3,
              coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0),
@@ -180,26 +195,23 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     params = dict(dim=dim, degree=degree, ncomp=ncomp, n_cells=n_cells, lo=lo, hi=hi, stokes=stokes,
                   grad_div=grad_div, gamma_grad_div=gamma_grad_div, beta=beta, center=tuple(center),
                   radius=radius, immersed_refine=immersed_refine, coupling_nq=coupling_nq)
-    pb = SyntheticProblem(params=params, _handle=C.c_void_p(h),
+    owner = _NativeHandle(h)
+    pb = SyntheticProblem(params=params, _handle=owner,
                           row_ranges=rr if row_ranges is not None else None)
     for name in ("A", "B", "Bt", "Mp", "Ct", "C", "M", "K"):
         nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
         rp, col, val = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
-        if lib.alfd_synth_matrix(pb._handle, name.encode(), C.byref(nr), C.byref(nc), C.byref(nnz),
+        if lib.alfd_synth_matrix(owner.ptr, name.encode(), C.byref(nr), C.byref(nc), C.byref(nnz),
                                  C.byref(rp), C.byref(col), C.byref(val)) != 0:
             continue
-        if nnz.value > 0:
-            cols = np.ctypeslib.as_array(col, shape=(nnz.value,))
-            vals = np.ctypeslib.as_array(val, shape=(nnz.value,))
-        else:
-            cols, vals = np.zeros(0, np.int32), np.zeros(0, np.float64)
-        pb.mats[name] = Csr(nr.value, nc.value, np.ctypeslib.as_array(rp, shape=(nr.value + 1,)), cols, vals)
+        pb.mats[name] = Csr(nr.value, nc.value, _view(rp, nr.value + 1, C.c_int64, np.int64, owner),
+                            _view(col, nnz.value, C.c_int32, np.int32, owner),
+                            _view(val, nnz.value, C.c_double, np.float64, owner))
     for name in ("f", "g", "rhs_p", "immersed_xyz"):
         n, data = C.c_int64(), C.POINTER(C.c_double)()
-        if lib.alfd_synth_vector(pb._handle, name.encode(), C.byref(n), C.byref(data)) != 0:
+        if lib.alfd_synth_vector(owner.ptr, name.encode(), C.byref(n), C.byref(data)) != 0:
             continue
-        pb.vecs[name] = (np.ctypeslib.as_array(data, shape=(n.value,)) if n.value > 0
-                         else np.zeros(0, np.float64))
+        pb.vecs[name] = _view(data, n.value, C.c_double, np.float64, owner)
     return pb
 
 

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "alfd_configure", "alfd_default_config", "alfd_setup", "alfd_precond_apply", "alfd_system_apply",
     "alfd_augment_rhs", "alfd_solve", "alfd_upload_rhs", "alfd_solve_resident", "alfd_download_solution",
     "alfd_get_history", "alfd_spmv", "alfd_dot", "alfd_matrix_lanes", "alfd_bench_spmv",
-    "alfd_enable_timing", "alfd_get_timing",
+    "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan",
 ]
 
 
@@ -82,6 +82,7 @@ def load_library():
         "alfd_bench_spmv": (C.c_int, [vp, C.c_int, i32, C.POINTER(dbl), C.POINTER(dbl)]),
         "alfd_enable_timing": (C.c_int, [vp, C.c_int]),
         "alfd_get_timing": (C.c_int, [vp, vp, vp, vp]),
+        "alfd_host_halo_plan": (C.c_int, [i64, vp, vp, C.c_int, C.c_int, vp, vp, i64, C.POINTER(i64), vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -252,6 +253,24 @@ class Context:
         self._ck(self._lib.alfd_get_timing(self._h, ms.ctypes.data, n.ctypes.data, b.ctypes.data))
         names = ["spmv_A", "spmv_other", "dot", "vec"]
         return {k: dict(ms=float(ms[i]), launches=int(n[i]), bytes=float(b[i])) for i, k in enumerate(names)}
+
+
+def host_halo_plan(col, col_offsets, rank):
+    """Host-only halo plan (no GPU): returns (col_local, halo_globals, recv_off)."""
+    lib = load_library()
+    col = np.ascontiguousarray(col, np.int32)
+    offs = np.ascontiguousarray(col_offsets, np.int64)
+    nranks = offs.size - 1
+    col_local = np.empty_like(col)
+    halo = np.empty(max(col.size, 1), np.int32)
+    n_halo = C.c_int64()
+    recv_off = np.zeros(nranks + 1, np.int64)
+    rc = lib.alfd_host_halo_plan(col.size, col.ctypes.data, offs.ctypes.data, nranks, rank,
+                                 col_local.ctypes.data, halo.ctypes.data, halo.size, C.byref(n_halo),
+                                 recv_off.ctypes.data)
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_halo_plan failed")
+    return col_local, halo[:n_halo.value].copy(), recv_off
 
 
 def upload_problem(ctx: Context, pb, cfg: _abi.Config) -> Context:

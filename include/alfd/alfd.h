@@ -177,6 +177,17 @@ int alfd_comm_unique_id(void *id_out, size_t bytes);
 int alfd_comm_init(alfd_ctx_t ctx, int rank, int nranks, const void *id, size_t bytes);
 int alfd_set_partition(alfd_ctx_t ctx, int nblocks, const int64_t *const *offsets /*[nblocks][nranks+1]*/);
 
+/* Host-only halo plan of one row-partitioned matrix (no GPU, no communication):
+ * rewrites the GLOBAL column indices of this rank's rows into the local index
+ * space [owned columns | halo entries], lists the halo's global ids (sorted,
+ * hence grouped by owning rank) and the receive prefix per owner
+ * (recv_off[nranks+1]).  alfd_set_matrix() runs the same routine internally;
+ * it is exported so that the partition logic can be tested on CPU ranks. */
+int alfd_host_halo_plan(int64_t nnz, const int32_t *col, const int64_t *col_offsets /*[nranks+1]*/,
+                        int nranks, int rank, int32_t *col_local /*[nnz]*/,
+                        int32_t *halo_globals /*[halo_capacity] or NULL*/, int64_t halo_capacity,
+                        int64_t *n_halo, int64_t *recv_off /*[nranks+1]*/);
+
 /* ------------------------------------------------------------------- upload
  * Replaces: linear_operator(SparseMatrix) captures, stokes...:923-929.
  * Caller keeps ownership of host arrays; the library copies to HBM.

@@ -1,0 +1,239 @@
+"""CPU tests of the oracle (test infrastructure) against independent SciPy /
+NumPy computations, the committed golden fixtures, and the known-answer test
+built from the reference's rational-approximation constants."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import cases
+from fictitious_domain_al_preconditioners_amd import _abi, problems
+from oracle import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built(built):
+    return built
+
+
+@pytest.mark.parametrize("lanes,vec", [(4, 1), (8, 1), (16, 1), (32, 1), (64, 1), (64, 2)])
+def test_spmv_every_lane_count_matches_scipy(lanes, vec):
+    pb = problems.stokes3d_sphere(5, 0)
+    for name in ("A", "B", "Ct", "Mp"):
+        m = pb.mats[name]
+        x = np.random.default_rng(7).uniform(-1, 1, m.ncols)
+        y, used = oracle.spmv(m, x, lanes=lanes, vec=vec)
+        assert used == lanes
+        ref = m.to_scipy() @ x
+        assert np.allclose(y, ref, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(ref).max()))
+
+
+def test_spmv_add_mode_skips_empty_rows_and_scales():
+    pb = problems.laplace2d_circle(16, 2)
+    ct = pb.mats["Ct"]          # mostly empty rows
+    x = np.random.default_rng(1).uniform(-1, 1, ct.ncols)
+    y0 = np.random.default_rng(2).uniform(-1, 1, ct.nrows)
+    y, _ = oracle.spmv(ct, x, y0, mode=1, alpha=2.5)
+    empty = np.diff(ct.row_ptr) == 0
+    assert np.array_equal(y[empty], y0[empty])
+    assert np.allclose(y, y0 + 2.5 * (ct.to_scipy() @ x), rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 511, 512, 4095, 4096, 4097, 12289, 1 << 18])
+def test_dot_matches_numpy_and_is_order_fixed(n):
+    rng = np.random.default_rng(n + 1)
+    x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    d = oracle.dot(x, y)
+    assert abs(d - float(np.dot(x, y))) <= 1e-13 * max(1.0, float(np.abs(x * y).sum()))
+    oracle.set_threads(1)
+    d1 = oracle.dot(x, y)
+    oracle.set_threads(4)
+    assert d1 == d == oracle.dot(x, y)      # thread count never changes the bits
+
+
+def _assemble(pb, cfg):
+    """Independent SciPy assembly of the augmented block system."""
+    A, Ct, C = (pb.mats[k].to_scipy() for k in ("A", "Ct", "C"))
+    W = sp.diags(pb.inv_w_diag_squared())
+    aug = A + cfg.gamma * (Ct @ W @ C)
+    if "B" in pb.mats:
+        B, Bt = pb.mats["B"].to_scipy(), pb.mats["Bt"].to_scipy()
+        return sp.bmat([[aug, Bt, Ct], [B, None, None], [C, None, None]]).tocsc()
+    return sp.bmat([[aug, Ct], [C, None]]).tocsc()
+
+
+@pytest.mark.parametrize("name", ["laplace2d_circle", "laplace3d_sphere", "stokes3d_sphere"])
+def test_system_apply_and_rhs_match_scipy(name):
+    pb, cfg = cases.case(name)
+    osys = oracle.system_from_problem(pb)
+    K = _assemble(pb, cfg)
+    src = cases.rng_blocks(pb, 3)
+    rc, dst = osys.system_apply(cfg, src)
+    assert rc == 0
+    ref = K @ np.concatenate(src)
+    got = np.concatenate(dst)
+    assert np.allclose(got, ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
+    rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+    w = pb.inv_w_diag_squared()
+    exp0 = cases.rhs_of(pb)[0] + cfg.gamma * (pb.mats["Ct"].to_scipy() @ (w * cases.rhs_of(pb)[-1]))
+    assert np.allclose(rhs[0], exp0, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(exp0).max()))
+
+
+def test_laplace_solution_matches_sparse_direct_solve():
+    """The 2x2 immersed Laplace system is non-singular: FGMRES must land on the
+    solution of an independent SuperLU factorisation."""
+    pb, cfg = cases.case("laplace2d_circle")
+    osys = oracle.system_from_problem(pb)
+    rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+    rc, x, res, hist = osys.solve(cfg, rhs)
+    assert rc == 0
+    xs = spla.spsolve(_assemble(pb, cfg), np.concatenate(rhs))
+    got = np.concatenate(x)
+    assert np.linalg.norm(got[:pb.block_sizes[0]] - xs[:pb.block_sizes[0]]) <= 1e-8 * np.linalg.norm(xs)
+    # Dirichlet constraint on the immersed curve: C u = g
+    cu = pb.mats["C"].to_scipy() @ x[0]
+    assert np.linalg.norm(cu - pb.vecs["g"]) <= 1e-8 * np.linalg.norm(pb.vecs["g"])
+
+
+@pytest.mark.parametrize("name", ["stokes2d_circle", "stokes3d_sphere"])
+def test_stokes_solution_satisfies_the_system(name):
+    pb, cfg = cases.case(name)
+    osys = oracle.system_from_problem(pb)
+    rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+    rc, x, res, hist = osys.solve(cfg, rhs)
+    assert rc == 0 and res.status == 0
+    r = _assemble(pb, cfg) @ np.concatenate(x) - np.concatenate(rhs)
+    # ReductionControl: |r| <= tol or |r| < reduce * |r0|; the Arnoldi estimate
+    # and the true residual agree to rounding
+    assert np.linalg.norm(r) <= 2 * max(cfg.outer.tol, cfg.outer.reduce * res.initial_residual)
+    assert np.isclose(np.linalg.norm(r), res.last_residual, rtol=1e-3)
+    assert np.isclose(hist[0], np.linalg.norm(np.concatenate(rhs)), rtol=1e-14)   # x0 = 0
+    assert np.all(np.diff(hist) <= 1e-12 * hist[0])     # GMRES residuals are monotone
+
+
+def test_preconditioner_vmult_algebra_stokes():
+    """...preconditioner.h:62-70 with exact inner solves: v2 = -g W^-1 u2,
+    v1 = -g_gd Mp^-1 u1, v0 = Aug^-1 (u0 - Bt v1 - Ct v2)."""
+    pb, cfg = cases.case("stokes3d_sphere")
+    cfg.inner = _abi.Control(_abi.CTRL_ABS, 5000, 1e-11, 0.0)
+    cfg.mp_inner = _abi.Control(_abi.CTRL_ABS, 500, 1e-13, 0.0)
+    osys = oracle.system_from_problem(pb)
+    u = cases.rng_blocks(pb, 5)
+    rc, v, res = osys.precond_apply(cfg, u)
+    assert rc == 0
+    w = pb.inv_w_diag_squared()
+    A, Ct, C, Bt, Mp = (pb.mats[k].to_scipy() for k in ("A", "Ct", "C", "Bt", "Mp"))
+    v2 = -cfg.gamma * w * u[2]
+    v1 = -cfg.gamma_grad_div * spla.spsolve(Mp.tocsc(), u[1])
+    aug = (A + cfg.gamma * (Ct @ sp.diags(w) @ C)).tocsc()
+    v0 = spla.spsolve(aug, u[0] - Bt @ v1 - Ct @ v2)
+    assert np.allclose(v[2], v2, rtol=1e-14, atol=0)
+    assert np.allclose(v[1], v1, rtol=1e-9, atol=1e-11 * np.abs(v1).max())
+    assert np.linalg.norm(v[0] - v0) <= 1e-8 * np.linalg.norm(v0)
+
+
+def test_diagonal_spd_variant_signs():
+    """...preconditioner.h:95-103: same blocks with '+' signs and no coupling."""
+    pb, cfg = cases.case("stokes3d_sphere")
+    cfg.variant = _abi.AL_STOKES_DIAG
+    osys = oracle.system_from_problem(pb)
+    u = cases.rng_blocks(pb, 6)
+    rc, v, _ = osys.precond_apply(cfg, u)
+    assert rc == 0
+    assert np.allclose(v[2], cfg.gamma * pb.inv_w_diag_squared() * u[2], rtol=1e-14)
+    cfg.variant = _abi.AL_STOKES
+    rc, vt, _ = osys.precond_apply(cfg, [np.zeros_like(u[0]), u[1], np.zeros_like(u[2])])
+    cfg.variant = _abi.AL_STOKES_DIAG
+    rc, vd, _ = osys.precond_apply(cfg, [np.zeros_like(u[0]), u[1], np.zeros_like(u[2])])
+    assert np.array_equal(vd[1], -vt[1])
+
+
+def test_stop_rules():
+    """SolverControl / ReductionControl / IterationNumberControl [EXT] semantics."""
+    pb, cfg = cases.case("stokes3d_sphere")
+    osys = oracle.system_from_problem(pb)
+    rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+    # outer max_steps reached -> NoConvergence, last_step == max_steps
+    cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 3, 1e-30, 1e-30)
+    rc, x, res, hist = osys.solve(cfg, rhs)
+    assert rc == _abi.E_NO_CONVERGENCE_OUTER and res.outer_iterations == 3 and len(hist) == 4
+    # fixed inner iterations: exactly max_steps CG steps per application, never a failure
+    pb, cfg = cases.case("stokes3d_sphere")
+    cfg.inner = _abi.Control(_abi.CTRL_FIXED_ITERS, 7, 0.0, 0.0)
+    rc, v, res = osys.precond_apply(cfg, cases.rng_blocks(pb, 9))
+    assert rc == 0 and res.inner_iterations == 7 and res.inner_failures == 0
+    # inner cap with the reference's throw-on-failure policy, and with ACCEPT
+    cfg.inner = _abi.Control(_abi.CTRL_ABS, 2, 1e-14, 0.0)
+    rc, v, res = osys.precond_apply(cfg, cases.rng_blocks(pb, 9))
+    assert rc == _abi.E_NO_CONVERGENCE_INNER
+    cfg.on_inner_failure = _abi.INNER_ACCEPT
+    rc, v, res = osys.precond_apply(cfg, cases.rng_blocks(pb, 9))
+    assert rc == 0 and res.inner_failures == 1 and res.inner_iterations == 2
+    # absolute tolerance already met by the initial residual -> 0 iterations
+    cfg = cases.case("stokes3d_sphere")[1]
+    cfg.outer = _abi.Control(_abi.CTRL_ABS, 10, 1e30, 0.0)
+    rc, x, res, hist = osys.solve(cfg, rhs)
+    assert rc == 0 and res.outer_iterations == 0 and len(hist) == 1
+
+
+@pytest.mark.parametrize("orth", [_abi.ORTH_MGS, _abi.ORTH_CGS, _abi.ORTH_CGS2])
+def test_orthogonalisation_variants_agree(orth):
+    pb, cfg = cases.case("laplace2d_circle")
+    cfg.orthogonalization = orth
+    osys = oracle.system_from_problem(pb)
+    rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+    rc, x, res, hist = osys.solve(cfg, rhs)
+    assert rc == 0
+    assert abs(res.outer_iterations - 17) <= 1
+
+
+def test_partition_emulated_dot_is_rank_ordered_sum():
+    """nranks_emulated: dots are per-rank canonical dots added in rank order."""
+    pb, cfg = cases.case("stokes3d_sphere")
+    rhs = cases.rhs_of(pb)
+    r1 = oracle.system_from_problem(pb, 1).solve(cfg, oracle.system_from_problem(pb).augment_rhs(cfg, rhs)[1])
+    r3 = oracle.system_from_problem(pb, 3).solve(cfg, oracle.system_from_problem(pb).augment_rhs(cfg, rhs)[1])
+    assert r1[0] == 0 and r3[0] == 0
+    assert r1[2].outer_iterations == r3[2].outer_iterations
+    assert np.allclose(r1[3], r3[3], rtol=1e-9)          # same algorithm, different rounding
+    assert not np.array_equal(r1[3], r3[3])
+
+
+@pytest.mark.parametrize("name", cases.ALL_CASES)
+def test_golden_fixtures(name):
+    """Committed iteration counts / residual histories (tests/golden/solves.json,
+    made by tests/golden/make_golden.py) -- bit-exact."""
+    gold = json.load(open(os.path.join(GOLDEN, "solves.json")))[name]
+    pb, cfg = cases.case(name)
+    assert pb.block_sizes == gold["block_sizes"]
+    osys = oracle.system_from_problem(pb)
+    rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+    rc, x, res, hist = osys.solve(cfg, rhs)
+    assert rc == 0
+    assert res.outer_iterations == gold["outer_iterations"]
+    assert res.inner_iterations == gold["inner_iterations"]
+    assert res.mp_iterations == gold["mp_iterations"]
+    assert [float(h).hex() for h in hist] == gold["history"]
+    assert float(res.lambda_max).hex() == gold["lambda_max"]
+
+
+def test_rational_constants_known_answer():
+    """rational_preconditioner.h:70-93: res0 + sum res_i/(x - p_i) is a rational
+    approximation of sqrt(x) on the scaled spectrum (lambda/rho in (0,1])."""
+    import ctypes as C
+    k = json.load(open(os.path.join(GOLDEN, "rational_constants.json")))
+    res, poles = np.array(k["res"]), np.array(k["poles"])
+    assert res.size == 21 and poles.size == 20 and np.all(poles < 0) and np.all(res[1:] < 0)
+    lib = oracle.lib()
+    for x in np.geomspace(1e-4, 1.0, 60):
+        r = lib.orc_rational_eval(20, res.ctypes.data, poles.ctypes.data, float(x))
+        assert abs(r - np.sqrt(x)) <= 2e-8 * np.sqrt(x)
+    # partial fractions with negative poles and residues => monotone increasing on x > 0
+    xs = np.geomspace(1e-6, 1.0, 200)
+    vals = [lib.orc_rational_eval(20, res.ctypes.data, poles.ctypes.data, float(x)) for x in xs]
+    assert np.all(np.diff(vals) > 0)
