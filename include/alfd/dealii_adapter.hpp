@@ -1,0 +1,213 @@
+// dealii_adapter.hpp -- header-only C++17 adapter that presents the C ABI of
+// alfd.h as deal.II-shaped classes, so that the reference's solve() functions
+// (immersed_laplace.cc:636-949, stokes_immersed_boundary.cc:918-1079) keep
+// their call-site shape:
+//
+//     alfd::dealii_adapter::System sys(/*device*/ 0);
+//     sys.set_matrix(ALFD_A,  stokes_matrix.block(0, 0));   // linear_operator(...) captures
+//     sys.set_matrix(ALFD_BT, stokes_matrix.block(0, 1));
+//     sys.set_matrix(ALFD_CT, coupling_matrix);
+//     sys.set_matrix(ALFD_MP, preconditioner_matrix.block(1, 1));
+//     sys.set_diag(ALFD_INVW, inverse_squares);             // DiagonalMatrix<Vector<double>>
+//     sys.set_diag(ALFD_MP_LUMPED_INV, pressure_diagonal_inv);
+//     sys.configure(cfg); sys.setup();
+//     BlockPreconditionerAugmentedLagrangianStokes P(sys);  // vmult(v, u) const
+//     SolverFGMRES<BlockVector<double>> solver(sys);        // solve(AA, x, b, P)
+//     solver.solve(sys.system_operator(), solution_block, system_rhs_block, P);
+//     outer_solver_control.last_step()  ->  solver.last_step()
+//
+// It is templated on the matrix / vector types and needs only the members the
+// reference uses: SparseMatrix: m(), n(), n_nonzero_elements(), begin(row) /
+// end(row) iterators with column() and value(); Vector: size(), begin();
+// BlockVector: n_blocks(), block(i).  tests/test_adapter.py compiles it against
+// a 60-line mock of those classes (deal.II itself is not installed here).
+//
+// Errors: a non-zero status from the ABI becomes a C++ exception --
+// alfd::dealii_adapter::NoConvergence (mirror of dealii::SolverControl::
+// NoConvergence, caught by the reference's main(): stokes...:1233-1254) or
+// alfd::dealii_adapter::Error (mirror of ExcMessage).
+#ifndef ALFD_DEALII_ADAPTER_HPP
+#define ALFD_DEALII_ADAPTER_HPP
+
+#include <algorithm>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "alfd/alfd.h"
+
+namespace alfd {
+namespace dealii_adapter {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int s, const std::string &what) : std::runtime_error(what), status(s) {}
+};
+// dealii::SolverControl::NoConvergence carries last_step / last_residual.
+struct NoConvergence : Error {
+  unsigned int last_step;
+  double last_residual;
+  NoConvergence(int s, const std::string &what, unsigned int step, double res)
+      : Error(s, what), last_step(step), last_residual(res) {}
+};
+
+class System {
+ public:
+  explicit System(int device_id = 0) {
+    const int rc = alfd_create(&ctx_, device_id);
+    if (rc != ALFD_OK) throw Error(rc, std::string("alfd_create: ") + alfd_strerror(rc));
+  }
+  ~System() {
+    if (ctx_) alfd_destroy(ctx_);
+  }
+  System(const System &) = delete;
+  System &operator=(const System &) = delete;
+
+  // deal.II stores the diagonal first in each row of a square matrix; the ABI
+  // wants ascending columns.  Copies once into CSR, uploads, frees.
+  template <class SparseMatrixType>
+  void set_matrix(int slot, const SparseMatrixType &M) {
+    const int64_t nrows = (int64_t)M.m();
+    std::vector<int64_t> rp(nrows + 1, 0);
+    std::vector<int32_t> col;
+    std::vector<double> val;
+    col.reserve(M.n_nonzero_elements());
+    val.reserve(M.n_nonzero_elements());
+    std::vector<std::pair<int32_t, double>> row;
+    for (int64_t r = 0; r < nrows; ++r) {
+      row.clear();
+      for (auto it = M.begin(r); it != M.end(r); ++it) row.emplace_back((int32_t)it->column(), it->value());
+      std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+      for (const auto &e : row) {
+        col.push_back(e.first);
+        val.push_back(e.second);
+      }
+      rp[r + 1] = (int64_t)col.size();
+    }
+    check(alfd_set_matrix(ctx_, slot, nrows, (int64_t)M.n(), rp.data(), col.data(), val.data()));
+  }
+
+  template <class VectorType>
+  void set_diag(int slot, const VectorType &d) {
+    check(alfd_set_diag(ctx_, slot, (int64_t)d.size(), &*d.begin()));
+  }
+
+  void configure(const alfd_config &cfg) {
+    cfg_ = cfg;
+    check(alfd_configure(ctx_, &cfg));
+  }
+  void setup() { check(alfd_setup(ctx_)); }
+  const alfd_config &config() const { return cfg_; }
+  alfd_ctx_t handle() const { return ctx_; }
+
+  // f += gamma Ct invW g  (stokes...:1012-1018)
+  template <class BlockVectorType>
+  void augment_rhs(BlockVectorType &rhs) {
+    std::vector<double *> p = ptrs(rhs);
+    check(alfd_augment_rhs(ctx_, p.data()));
+  }
+
+  // The block_operator AA (stokes...:1000-1003) as an object with vmult().
+  class SystemOperator {
+   public:
+    explicit SystemOperator(System &s) : sys_(&s) {}
+    template <class BlockVectorType>
+    void vmult(BlockVectorType &dst, const BlockVectorType &src) const {
+      std::vector<const double *> s = cptrs(src);
+      std::vector<double *> d = ptrs(dst);
+      sys_->check(alfd_system_apply(sys_->ctx_, s.data(), d.data()));
+    }
+    System *system() const { return sys_; }
+
+   private:
+    System *sys_;
+  };
+  SystemOperator system_operator() { return SystemOperator(*this); }
+
+  void check(int rc, unsigned int step = 0, double res = 0) const {
+    if (rc == ALFD_OK) return;
+    const std::string msg = std::string(alfd_strerror(rc)) + ": " + alfd_last_error(ctx_);
+    if (rc == ALFD_E_NO_CONVERGENCE_OUTER || rc == ALFD_E_NO_CONVERGENCE_INNER)
+      throw NoConvergence(rc, msg, step, res);
+    throw Error(rc, msg);
+  }
+
+  template <class BlockVectorType>
+  static std::vector<double *> ptrs(BlockVectorType &v) {
+    std::vector<double *> p(v.n_blocks());
+    for (unsigned int b = 0; b < v.n_blocks(); ++b) p[b] = &*v.block(b).begin();
+    return p;
+  }
+  template <class BlockVectorType>
+  static std::vector<const double *> cptrs(const BlockVectorType &v) {
+    std::vector<const double *> p(v.n_blocks());
+    for (unsigned int b = 0; b < v.n_blocks(); ++b) p[b] = &*v.block(b).begin();
+    return p;
+  }
+
+ private:
+  alfd_ctx_t ctx_ = nullptr;
+  alfd_config cfg_{};
+  friend class SystemOperator;
+};
+
+// Common base of the preconditioner classes: depth-1 drop-in, deal.II keeps
+// its own SolverFGMRES and calls vmult() once per outer iteration.
+template <int Variant>
+class ALPreconditioner {
+ public:
+  explicit ALPreconditioner(System &s) : sys_(&s) {
+    if (s.config().variant != Variant) throw Error(ALFD_E_INVALID, "context configured for another variant");
+  }
+  // void vmult(BlockVector<double>& v, const BlockVector<double>& u) const
+  template <class BlockVectorType>
+  void vmult(BlockVectorType &v, const BlockVectorType &u) const {
+    std::vector<const double *> s = System::cptrs(u);
+    std::vector<double *> d = System::ptrs(v);
+    alfd_result res{};
+    sys_->check(alfd_precond_apply(sys_->handle(), s.data(), d.data(), &res));
+    last_ = res;
+  }
+  const alfd_result &last_result() const { return last_; }
+  System *system() const { return sys_; }
+
+ private:
+  System *sys_;
+  mutable alfd_result last_{};
+};
+
+// augmented_lagrangian_preconditioner.h:14-42, :44-79, :81-110
+using BlockPreconditionerAugmentedLagrangian = ALPreconditioner<ALFD_AL2>;
+using BlockPreconditionerAugmentedLagrangianStokes = ALPreconditioner<ALFD_AL_STOKES>;
+using BlockPreconditionerAugmentedLagrangianDiagonal = ALPreconditioner<ALFD_AL_STOKES_DIAG>;
+
+// Depth-2 drop-in for SolverFGMRES<BlockVector<double>> (stokes...:1067-1074):
+// the whole solve runs on the GPU; the stop rule is alfd_config::outer.
+template <class BlockVectorType>
+class SolverFGMRES {
+ public:
+  explicit SolverFGMRES(System &s) : sys_(&s) {}
+  template <class MatrixType, class PreconditionerType>
+  void solve(const MatrixType &A, BlockVectorType &x, const BlockVectorType &b, const PreconditionerType &P) {
+    if (A.system() != sys_ || P.system() != sys_)
+      throw Error(ALFD_E_INVALID, "operator, preconditioner and solver must share one System");
+    std::vector<const double *> rhs = System::cptrs(b);
+    std::vector<double *> sol = System::ptrs(x);
+    const int rc = alfd_solve(sys_->handle(), rhs.data(), sol.data(), &last_);
+    sys_->check(rc, (unsigned int)last_.outer_iterations, last_.last_residual);
+  }
+  unsigned int last_step() const { return (unsigned int)last_.outer_iterations; }   // SolverControl::last_step()
+  double last_value() const { return last_.last_residual; }                        // SolverControl::last_value()
+  const alfd_result &last_result() const { return last_; }
+
+ private:
+  System *sys_;
+  alfd_result last_{};
+};
+
+}  // namespace dealii_adapter
+}  // namespace alfd
+
+#endif  // ALFD_DEALII_ADAPTER_HPP
