@@ -26,6 +26,8 @@
 #include <cstring>
 #include <memory>
 #include <climits>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -118,6 +120,7 @@ struct alfd_ctx {
   // partition / comm
   int rank = 0, nranks = 1;
   ncclComm_t nccl = nullptr;
+  struct alfd_local_group *local = nullptr;  // in-process rank group (single-GPU emulation of N ranks)
   std::vector<std::vector<int64_t>> part;  // [block][nranks+1] global offsets
   // layout
   int nblocks = 0;
@@ -157,6 +160,92 @@ struct alfd_ctx {
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8;
   int64_t ntot() const { return off[nblocks]; }
 };
+
+// ---------------------------------------------------------------------------
+// In-process rank group: N contexts in ONE process (one host thread per rank)
+// exchange through device-to-device copies and a host barrier instead of RCCL.
+// It exists so that everything of the multi-rank path except the literal RCCL
+// calls (halo plans, pack kernels, halo SpMV, ordered reductions, setup
+// protocol) can be executed on a single-GPU box; one process per GPU over
+// RCCL remains the production configuration.
+struct alfd_local_group {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  std::vector<const void *> buf;            // per rank: published buffer
+  std::vector<const int64_t *> off;         // per rank: published prefix (alltoallv)
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long g = generation;
+    if (++arrived == n) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != g; });
+    }
+  }
+};
+
+namespace alfd {
+
+// all-gather of `bytes` per rank, device buffers, result ordered by rank
+static int comm_allgather(alfd_ctx *ctx, const void *send, void *recv, size_t bytes) {
+  if (ctx->local) {
+    alfd_local_group *g = ctx->local;
+    HIPC(hipStreamSynchronize(ctx->stream));
+    g->buf[ctx->rank] = send;
+    g->barrier();
+    for (int p = 0; p < g->n; ++p)
+      HIPC(hipMemcpyAsync((char *)recv + (size_t)p * bytes, g->buf[p], bytes, hipMemcpyDeviceToDevice,
+                          ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    g->barrier();
+    return ALFD_OK;
+  }
+  if (ncclAllGather(send, recv, bytes, ncclChar, ctx->nccl, ctx->stream) != ncclSuccess)
+    return ctx->err = "ncclAllGather failed", ALFD_E_COMM;
+  return ALFD_OK;
+}
+
+// personalised exchange: rank r sends sendbuf[send_off[p] .. send_off[p+1]) to p and
+// receives recvbuf[recv_off[p] .. recv_off[p+1]) from p (element size `es` bytes)
+static int comm_alltoallv(alfd_ctx *ctx, const void *sendbuf, const int64_t *send_off, void *recvbuf,
+                          const int64_t *recv_off, size_t es) {
+  if (ctx->local) {
+    alfd_local_group *g = ctx->local;
+    HIPC(hipStreamSynchronize(ctx->stream));
+    g->buf[ctx->rank] = sendbuf;
+    g->off[ctx->rank] = send_off;
+    g->barrier();
+    for (int p = 0; p < g->n; ++p) {
+      const int64_t nr = recv_off[p + 1] - recv_off[p];
+      if (nr > 0)  // what p sends to me starts at p's send_off[my rank]
+        HIPC(hipMemcpyAsync((char *)recvbuf + (size_t)recv_off[p] * es,
+                            (const char *)g->buf[p] + (size_t)g->off[p][ctx->rank] * es, (size_t)nr * es,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIPC(hipStreamSynchronize(ctx->stream));
+    g->barrier();
+    return ALFD_OK;
+  }
+  if (ncclGroupStart() != ncclSuccess) return ctx->err = "ncclGroupStart", ALFD_E_COMM;
+  for (int p = 0; p < ctx->nranks; ++p) {
+    const int64_t ns = send_off[p + 1] - send_off[p], nr = recv_off[p + 1] - recv_off[p];
+    if (ns > 0 && ncclSend((const char *)sendbuf + (size_t)send_off[p] * es, (size_t)ns * es, ncclChar, p,
+                           ctx->nccl, ctx->stream) != ncclSuccess)
+      return ctx->err = "ncclSend", ALFD_E_COMM;
+    if (nr > 0 && ncclRecv((char *)recvbuf + (size_t)recv_off[p] * es, (size_t)nr * es, ncclChar, p, ctx->nccl,
+                           ctx->stream) != ncclSuccess)
+      return ctx->err = "ncclRecv", ALFD_E_COMM;
+  }
+  if (ncclGroupEnd() != ncclSuccess) return ctx->err = "ncclGroupEnd", ALFD_E_COMM;
+  return ALFD_OK;
+}
+
+}  // namespace alfd
 
 namespace alfd {
 
@@ -295,7 +384,9 @@ static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, do
                 const double *d = nullptr, double *y2 = nullptr) {
   DevCsr &m = ctx->mat[slot];
   if (!m.present) return ctx->err = "matrix slot " + std::to_string(slot) + " not set", ALFD_E_NOT_SETUP;
-  if (ctx->nranks > 1 && (m.n_halo > 0 || m.send_off.back() > 0)) RC(halo_exchange(ctx, m, x));
+  // RCCL send/recv pairs can be skipped by ranks with nothing to exchange; the
+  // barrier-based in-process group needs every rank in every exchange.
+  if (ctx->nranks > 1 && (ctx->local || m.n_halo > 0 || m.send_off.back() > 0)) RC(halo_exchange(ctx, m, x));
   if (m.sparse && epi != 1) {
     // rows outside the list are structurally empty: their result is 0
     HIPC(hipMemsetAsync(y, 0, m.nrows * sizeof(double), ctx->stream));
@@ -341,9 +432,7 @@ static int finish_dots(alfd_ctx *ctx, int64_t nb, int count, int out, int fin) {
   hipLaunchKernelGGL(dot_final_kernel, dim3(count), dim3(kBlock), 0, ctx->stream, ctx->partial, nb,
                      ctx->pstride, ctx->sc, (int)S_STAGE, (int)FIN_STORE);
   HIPC(hipGetLastError());
-  if (ncclAllGather(ctx->sc + S_STAGE, ctx->gather, count, ncclDouble, ctx->nccl, ctx->stream) !=
-      ncclSuccess)
-    return ctx->err = "ncclAllGather failed", ALFD_E_COMM;
+  RC(comm_allgather(ctx, ctx->sc + S_STAGE, ctx->gather, (size_t)count * sizeof(double)));
   const int tgt = fin == FIN_STORE ? out : (int)S_TMP;
   hipLaunchKernelGGL(rank_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->gather, ctx->nranks, count,
                      ctx->sc, tgt);
@@ -669,15 +758,7 @@ static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x) {
                        nsend, m.send_idx, x, m.send_buf);
     HIPC(hipGetLastError());
   }
-  if (ncclGroupStart() != ncclSuccess) return ctx->err = "ncclGroupStart", ALFD_E_COMM;
-  for (int p = 0; p < ctx->nranks; ++p) {
-    const int64_t ns = m.send_off[p + 1] - m.send_off[p], nr = m.recv_off[p + 1] - m.recv_off[p];
-    if (ns > 0 && ncclSend(m.send_buf + m.send_off[p], ns, ncclDouble, p, ctx->nccl, ctx->stream) != ncclSuccess)
-      return ctx->err = "ncclSend", ALFD_E_COMM;
-    if (nr > 0 && ncclRecv(m.halo + m.recv_off[p], nr, ncclDouble, p, ctx->nccl, ctx->stream) != ncclSuccess)
-      return ctx->err = "ncclRecv", ALFD_E_COMM;
-  }
-  if (ncclGroupEnd() != ncclSuccess) return ctx->err = "ncclGroupEnd", ALFD_E_COMM;
+  RC(comm_alltoallv(ctx, m.send_buf, m.send_off.data(), m.halo, m.recv_off.data(), sizeof(double)));
   return ALFD_OK;
 }
 
@@ -847,8 +928,27 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
   m.nnz = rp[nrows];
   int64_t nonempty = 0;
   for (int64_t r = 0; r < nrows; ++r) nonempty += rp[r + 1] > rp[r];
-  choose_lanes(m, nonempty);
   m.sparse = nonempty * 2 < nrows;
+  if (ctx->nranks > 1) {
+    // lanes-per-row follows the GLOBAL matrix (so every rank, and the oracle, use one L)
+    int64_t mine[2] = {m.nnz, nonempty};
+    std::vector<int64_t> all(2 * (size_t)ctx->nranks);
+    int64_t *d_m = nullptr, *d_a = nullptr;
+    RC(dev_alloc(ctx, &d_m, 2));
+    RC(dev_alloc(ctx, &d_a, 2 * (int64_t)ctx->nranks));
+    HIPC(hipMemcpyAsync(d_m, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    RC(comm_allgather(ctx, d_m, d_a, sizeof(mine)));
+    HIPC(hipMemcpyAsync(all.data(), d_a, all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    int64_t gn = 0, ge = 0;
+    for (int p = 0; p < ctx->nranks; ++p) gn += all[2 * p], ge += all[2 * p + 1];
+    DevCsr tmp;
+    tmp.nnz = gn;
+    choose_lanes(tmp, ge);
+    m.L = tmp.L;
+  } else {
+    choose_lanes(m, nonempty);
+  }
   const int32_t *col_up = col;
   std::vector<int32_t> remap;
   m.n_local_cols = (int32_t)ncols;
@@ -872,8 +972,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     RC(dev_alloc(ctx, &d_cl, ctx->nranks));
     RC(dev_alloc(ctx, &d_ca, (int64_t)ctx->nranks * ctx->nranks));
     HIPC(hipMemcpyAsync(d_cl, cnt_local.data(), ctx->nranks * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (ncclAllGather(d_cl, d_ca, ctx->nranks, ncclInt32, ctx->nccl, ctx->stream) != ncclSuccess)
-      return ctx->err = "ncclAllGather(counts)", ALFD_E_COMM;
+    RC(comm_allgather(ctx, d_cl, d_ca, (size_t)ctx->nranks * 4));
     HIPC(hipMemcpyAsync(cnt_all.data(), d_ca, cnt_all.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
     m.send_off.assign(ctx->nranks + 1, 0);
@@ -885,13 +984,8 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     RC(dev_alloc(ctx, &d_req, m.n_halo));
     RC(dev_alloc(ctx, &d_want, nsend));
     HIPC(hipMemcpyAsync(d_req, hal.data(), m.n_halo * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (ncclGroupStart() != ncclSuccess) return ctx->err = "ncclGroupStart", ALFD_E_COMM;
-    for (int p = 0; p < ctx->nranks; ++p) {
-      const int64_t nr = m.recv_off[p + 1] - m.recv_off[p], ns = m.send_off[p + 1] - m.send_off[p];
-      if (nr > 0) ncclSend(d_req + m.recv_off[p], nr, ncclInt32, p, ctx->nccl, ctx->stream);
-      if (ns > 0) ncclRecv(d_want + m.send_off[p], ns, ncclInt32, p, ctx->nccl, ctx->stream);
-    }
-    if (ncclGroupEnd() != ncclSuccess) return ctx->err = "ncclGroupEnd", ALFD_E_COMM;
+    // I send my wanted-id list slices (grouped by owner), I receive what peers want from me
+    RC(comm_alltoallv(ctx, d_req, m.recv_off.data(), d_want, m.send_off.data(), sizeof(int32_t)));
     std::vector<int32_t> want(nsend);
     HIPC(hipMemcpyAsync(want.data(), d_want, nsend * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
@@ -1027,11 +1121,12 @@ static int setup(alfd_ctx *ctx) {
       default: ALFD_DIAG(64); break;
     }
 #undef ALFD_DIAG
+    // a rank with no coupling rows of its own may still own W entries its peers need
+    if (ctx->nranks > 1 && (ctx->local || Ct.n_halo > 0 || Ct.send_off.back() > 0)) {
+      DevCsr &Ctm = ctx->mat[ALFD_CT];
+      RC(halo_exchange(ctx, Ctm, ctx->diag[ALFD_INVW]));
+    }
     if (Ct.n_list > 0) {
-      if (ctx->nranks > 1 && (Ct.n_halo > 0 || Ct.send_off.back() > 0)) {
-        DevCsr &Ctm = ctx->mat[ALFD_CT];
-        RC(halo_exchange(ctx, Ctm, ctx->diag[ALFD_INVW]));
-      }
       hipLaunchKernelGGL(aug_diag_rows_kernel, dim3((unsigned)((Ct.n_list + 255) / 256)), dim3(256), 0,
                          ctx->stream, Ct.n_list, Ct.rp, Ct.col, Ct.val, Ct.sparse ? Ct.rows : nullptr,
                          ctx->diag[ALFD_INVW], Ct.halo, Ct.n_local_cols, ctx->s_aug);
@@ -1191,6 +1286,31 @@ int alfd_comm_init(alfd_ctx_t ctx, int rank, int nranks, const void *id, size_t 
   std::memcpy(&uid, id, sizeof(uid));
   if (ncclCommInitRank(&ctx->nccl, nranks, uid, rank) != ncclSuccess)
     return ctx->err = "ncclCommInitRank failed", ALFD_E_COMM;
+  return ALFD_OK;
+}
+
+int alfd_local_group_create(int nranks, alfd_local_group **out) {
+  if (!out || nranks < 1) return ALFD_E_INVALID;
+  alfd_local_group *g = new alfd_local_group;
+  g->n = nranks;
+  g->buf.assign(nranks, nullptr);
+  g->off.assign(nranks, nullptr);
+  *out = g;
+  return ALFD_OK;
+}
+
+int alfd_local_group_destroy(alfd_local_group *g) {
+  if (!g) return ALFD_E_INVALID;
+  delete g;
+  return ALFD_OK;
+}
+
+int alfd_comm_init_local(alfd_ctx_t ctx, alfd_local_group *g, int rank) {
+  CHECK_CTX();
+  if (!g || rank < 0 || rank >= g->n) return ALFD_E_INVALID;
+  ctx->rank = rank;
+  ctx->nranks = g->n;
+  ctx->local = g->n > 1 ? g : nullptr;
   return ALFD_OK;
 }
 

@@ -26,7 +26,8 @@ ABI_SYMBOLS = [
     "alfd_configure", "alfd_default_config", "alfd_setup", "alfd_precond_apply", "alfd_system_apply",
     "alfd_augment_rhs", "alfd_solve", "alfd_upload_rhs", "alfd_solve_resident", "alfd_download_solution",
     "alfd_get_history", "alfd_spmv", "alfd_dot", "alfd_matrix_lanes", "alfd_bench_spmv",
-    "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan",
+    "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan", "alfd_local_group_create",
+    "alfd_local_group_destroy", "alfd_comm_init_local",
 ]
 
 
@@ -83,6 +84,9 @@ def load_library():
         "alfd_enable_timing": (C.c_int, [vp, C.c_int]),
         "alfd_get_timing": (C.c_int, [vp, vp, vp, vp]),
         "alfd_host_halo_plan": (C.c_int, [i64, vp, vp, C.c_int, C.c_int, vp, vp, i64, C.POINTER(i64), vp]),
+        "alfd_local_group_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "alfd_local_group_destroy": (C.c_int, [vp]),
+        "alfd_comm_init_local": (C.c_int, [vp, vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -137,6 +141,9 @@ class Context:
 
     def comm_init(self, rank, nranks, unique_id: bytes):
         self._ck(self._lib.alfd_comm_init(self._h, rank, nranks, unique_id, len(unique_id)))
+
+    def comm_init_local(self, group, rank):
+        self._ck(self._lib.alfd_comm_init_local(self._h, group, rank))
 
     def set_partition(self, offsets):
         arrs = [np.ascontiguousarray(o, np.int64) for o in offsets]
@@ -253,6 +260,23 @@ class Context:
         self._ck(self._lib.alfd_get_timing(self._h, ms.ctypes.data, n.ctypes.data, b.ctypes.data))
         names = ["spmv_A", "spmv_other", "dot", "vec"]
         return {k: dict(ms=float(ms[i]), launches=int(n[i]), bytes=float(b[i])) for i, k in enumerate(names)}
+
+
+class LocalGroup:
+    """In-process rank group (alfd_local_group): N contexts driven by N threads."""
+
+    def __init__(self, nranks):
+        self._lib = load_library()
+        self.handle = C.c_void_p()
+        rc = self._lib.alfd_local_group_create(nranks, C.byref(self.handle))
+        if rc != _abi.OK:
+            raise AlfdError(rc, "alfd_local_group_create failed")
+        self.nranks = nranks
+
+    def close(self):
+        if self.handle:
+            self._lib.alfd_local_group_destroy(self.handle)
+            self.handle = None
 
 
 def host_halo_plan(col, col_offsets, rank):

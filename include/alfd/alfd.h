@@ -177,6 +177,16 @@ int alfd_comm_unique_id(void *id_out, size_t bytes);
 int alfd_comm_init(alfd_ctx_t ctx, int rank, int nranks, const void *id, size_t bytes);
 int alfd_set_partition(alfd_ctx_t ctx, int nblocks, const int64_t *const *offsets /*[nblocks][nranks+1]*/);
 
+/* In-process rank group: N contexts of ONE process (one host thread per rank,
+ * typically all on one GPU) exchange through device-to-device copies and a host
+ * barrier instead of RCCL.  Test vehicle for the multi-rank path on a single-GPU
+ * box; collective calls (alfd_set_matrix, alfd_setup, alfd_solve, ...) must
+ * then be issued by all ranks concurrently, one thread each. */
+typedef struct alfd_local_group alfd_local_group;
+int alfd_local_group_create(int nranks, alfd_local_group **group);
+int alfd_local_group_destroy(alfd_local_group *group);
+int alfd_comm_init_local(alfd_ctx_t ctx, alfd_local_group *group, int rank);
+
 /* Host-only halo plan of one row-partitioned matrix (no GPU, no communication):
  * rewrites the GLOBAL column indices of this rank's rows into the local index
  * space [owned columns | halo entries], lists the halo's global ids (sorted,

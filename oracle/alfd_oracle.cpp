@@ -202,8 +202,17 @@ struct Control {
   }
 };
 
+// Emulated multi-rank row partition: every reduction is a sum, in rank order,
+// of the ranks' local canonical reductions (what the library does with an
+// all-gather + ordered sum).
+struct Partition {
+  int nranks = 1;
+  std::vector<std::vector<int64_t>> offs;  // [block][nranks+1]
+};
+
 // --------------------------------------------------------------- problem
 struct Problem {
+  Partition pt;
   Csr mat[ALFD_NSLOTS];
   const double *diag[ALFD_NDIAGS] = {nullptr, nullptr};
   int nblocks = 0;
@@ -219,6 +228,18 @@ struct Problem {
   int status = ALFD_OK;
   int64_t ntot() const { return off[nblocks]; }
 };
+
+// dot of two vectors of block `blk` under the emulated partition
+static double bdot(const Problem &P, int blk, const double *x, const double *y) {
+  if (P.pt.nranks <= 1) return dot(P.n[blk], x, y);
+  double total = 0.0;
+  for (int r = 0; r < P.pt.nranks; ++r) {
+    const int64_t g0 = P.pt.offs[blk][r], nl = P.pt.offs[blk][r + 1] - g0;
+    const double d = dot(nl, x + g0, y + g0);
+    total = r == 0 ? d : total + d;
+  }
+  return total;
+}
 
 static void transpose_into(const Csr &a, Csr &t) {
   t.nrows = a.ncols;
@@ -309,19 +330,19 @@ struct ChebPrec {
 
 // deal.II SolverCG through inverse_operator: zero initial guess [EXT].
 template <class Op, class Prec>
-static State pcg(Op &op, Prec &prec, const alfd_control &ctrl, const double *b, double *x, int64_t n,
-                 int &its, double &last_res, int log_level, const char *tag) {
+static State pcg(const Problem &P, int blk, Op &op, Prec &prec, const alfd_control &ctrl, const double *b,
+                 double *x, int64_t n, int &its, double &last_res, int log_level, const char *tag) {
   std::vector<double> r(b, b + n), z(n), p(n), Ap(n);
   std::fill(x, x + n, 0.0);
   Control sc{ctrl};
-  double res = std::sqrt(dot(n, r.data(), r.data()));
+  double res = std::sqrt(bdot(P, blk, r.data(), r.data()));
   State st = sc.check(0, res);
   its = 0;
   double rz_old = 0.0;
   while (st == ITERATE) {
     ++its;
     prec(r.data(), z.data(), n);
-    const double rz = dot(n, r.data(), z.data());
+    const double rz = bdot(P, blk, r.data(), z.data());
     if (its > 1) {
       const double beta = rz / rz_old;
       xpby(n, z.data(), beta, p.data());
@@ -329,11 +350,11 @@ static State pcg(Op &op, Prec &prec, const alfd_control &ctrl, const double *b, 
       std::memcpy(p.data(), z.data(), n * sizeof(double));
     }
     op(p.data(), Ap.data());
-    const double pAp = dot(n, p.data(), Ap.data());
+    const double pAp = bdot(P, blk, p.data(), Ap.data());
     const double alpha = rz / pAp;
     axpy(n, alpha, p.data(), x);
     axpy(n, -alpha, Ap.data(), r.data());
-    res = std::sqrt(dot(n, r.data(), r.data()));
+    res = std::sqrt(bdot(P, blk, r.data(), r.data()));
     st = sc.check(its, res);
     rz_old = rz;
     if (log_level >= 3) std::printf("DEAL:%s:cg::Check %d\t%.17g\n", tag, its, res);
@@ -350,14 +371,14 @@ static int inner_solve_aug(Problem &P, const double *b, double *x) {
   const int64_t n = P.n[0];
   if (P.cfg.inner_prec == ALFD_PREC_IDENTITY) {
     IdentityPrec pr;
-    st = pcg(op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
+    st = pcg(P, 0, op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
   } else if (P.cfg.inner_prec == ALFD_PREC_JACOBI) {
     DiagPrec pr{P.dinv_aug.data()};
-    st = pcg(op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
+    st = pcg(P, 0, op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
   } else {
     AugOp op2{P, {}};
     ChebPrec pr{P, op2, {}, {}, {}};
-    st = pcg(op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
+    st = pcg(P, 0, op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
   }
   P.inner_its += its;
   if (st == FAILURE) {
@@ -373,7 +394,7 @@ static int inner_solve_mp(Problem &P, const double *b, double *x) {
   DiagPrec pr{P.diag[ALFD_MP_LUMPED_INV]};
   int its = 0;
   double res = 0;
-  State st = pcg(op, pr, P.cfg.mp_inner, b, x, P.n[1], its, res, P.cfg.log_level, "mp");
+  State st = pcg(P, 1, op, pr, P.cfg.mp_inner, b, x, P.n[1], its, res, P.cfg.log_level, "mp");
   P.mp_its += its;
   if (st == FAILURE) {
     if (std::isnan(res)) return ALFD_E_BREAKDOWN;
@@ -408,11 +429,11 @@ static void setup(Problem &P) {
     AugOp op{P, {}};
     double lam = 0.0;
     for (int it = 0; it < P.cfg.cheb_power_its; ++it) {
-      const double nv = std::sqrt(dot(n, v.data(), v.data()));
+      const double nv = std::sqrt(bdot(P, 0, v.data(), v.data()));
       scale(n, 1.0 / nv, v.data());
       op(v.data(), wv.data());
       pmul(n, P.dinv_aug.data(), wv.data(), wv.data());
-      lam = std::sqrt(dot(n, wv.data(), wv.data()));
+      lam = std::sqrt(bdot(P, 0, wv.data(), wv.data()));
       v.swap(wv);
     }
     P.lambda_max = lam * P.cfg.cheb_safety;
@@ -484,14 +505,9 @@ static int system_apply(Problem &P, const double *x, double *y) {
 }
 
 // ------------------------------------------------------------------ FGMRES
-// nranks_emul > 1: dots are summed per emulated rank (contiguous equal row
-// split of every block, chunk-aligned local layouts), in rank order.
-struct Partition {
-  int nranks = 1;
-  std::vector<std::vector<int64_t>> offs;  // [block][nranks+1]
-};
-
-static double pdot(const Problem &P, const Partition &pt, const double *x, const double *y) {
+// nranks > 1: dots are summed per emulated rank (chunk-aligned local layouts), in rank order.
+static double pdot(const Problem &P, const double *x, const double *y) {
+  const Partition &pt = P.pt;
   if (pt.nranks <= 1) return dot(P.ntot(), x, y);
   double total = 0.0;
   for (int r = 0; r < pt.nranks; ++r) {
@@ -513,7 +529,7 @@ static double pdot(const Problem &P, const Partition &pt, const double *x, const
   return total;
 }
 
-static int fgmres(Problem &P, const Partition &pt, const double *b, double *x, alfd_result *out,
+static int fgmres(Problem &P, const double *b, double *x, alfd_result *out,
                   std::vector<double> &history) {
   const alfd_config &c = P.cfg;
   const int m = c.restart;
@@ -529,7 +545,7 @@ static int fgmres(Problem &P, const Partition &pt, const double *b, double *x, a
     int rc = system_apply(P, x, V[0].data());
     if (rc != ALFD_OK) return rc;
     sub_from(N, b, V[0].data());  // v0 = b - AA x
-    res = std::sqrt(pdot(P, pt, V[0].data(), V[0].data()));
+    res = std::sqrt(pdot(P, V[0].data(), V[0].data()));
     st = sc.check(k, res);
     if (k == 0) history.push_back(res);
     if (c.log_level >= 2) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
@@ -546,19 +562,19 @@ static int fgmres(Problem &P, const Partition &pt, const double *b, double *x, a
       // orthogonalise wv against V[0..j]
       if (c.orthogonalization == ALFD_ORTH_MGS) {
         for (int i = 0; i <= j; ++i) {
-          h[i] = pdot(P, pt, V[i].data(), wv);
+          h[i] = pdot(P, V[i].data(), wv);
           axpy(N, -h[i], V[i].data(), wv);
         }
       } else {
-        for (int i = 0; i <= j; ++i) h[i] = pdot(P, pt, V[i].data(), wv);
+        for (int i = 0; i <= j; ++i) h[i] = pdot(P, V[i].data(), wv);
         for (int i = 0; i <= j; ++i) axpy(N, -h[i], V[i].data(), wv);
         if (c.orthogonalization == ALFD_ORTH_CGS2) {
-          for (int i = 0; i <= j; ++i) h2[i] = pdot(P, pt, V[i].data(), wv);
+          for (int i = 0; i <= j; ++i) h2[i] = pdot(P, V[i].data(), wv);
           for (int i = 0; i <= j; ++i) axpy(N, -h2[i], V[i].data(), wv);
           for (int i = 0; i <= j; ++i) h[i] = h[i] + h2[i];
         }
       }
-      h[j + 1] = std::sqrt(pdot(P, pt, wv, wv));
+      h[j + 1] = std::sqrt(pdot(P, wv, wv));
       if (h[j + 1] != 0.0) scale(N, 1.0 / h[j + 1], wv);
       // Givens
       for (int i = 0; i < j; ++i) {
@@ -616,6 +632,7 @@ typedef struct orc_problem {
   int32_t nblocks;
   int32_t nranks_emulated;
   int64_t n[ALFD_MAX_BLOCKS];
+  const int64_t *part_offsets[ALFD_MAX_BLOCKS];  // optional [nranks+1] per block; NULL = even split
 } orc_problem;
 
 static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P) {
@@ -644,6 +661,15 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
   }
   for (int s = 0; s < ALFD_NSLOTS; ++s)
     if (P.mat[s].present()) orc::choose_lanes(P.mat[s]);
+  P.pt.nranks = op->nranks_emulated > 1 ? op->nranks_emulated : 1;
+  if (P.pt.nranks > 1) {
+    P.pt.offs.resize(P.nblocks);
+    for (int b = 0; b < P.nblocks; ++b) {
+      P.pt.offs[b].resize(P.pt.nranks + 1);
+      for (int r = 0; r <= P.pt.nranks; ++r)
+        P.pt.offs[b][r] = op->part_offsets[b] ? op->part_offsets[b][r] : P.n[b] * r / P.pt.nranks;
+    }
+  }
   orc::setup(P);
   return ALFD_OK;
 }
@@ -728,21 +754,12 @@ int orc_solve(const orc_problem *op, const alfd_config *cfg, const double *const
   orc::Problem P;
   int rc = build(op, cfg, P);
   if (rc != ALFD_OK) return rc;
-  orc::Partition pt;
-  pt.nranks = op->nranks_emulated > 1 ? op->nranks_emulated : 1;
-  if (pt.nranks > 1) {
-    pt.offs.resize(P.nblocks);
-    for (int b = 0; b < P.nblocks; ++b) {
-      pt.offs[b].resize(pt.nranks + 1);
-      for (int r = 0; r <= pt.nranks; ++r) pt.offs[b][r] = P.n[b] * r / pt.nranks;
-    }
-  }
   std::vector<double> bb, xx, hist;
   pack(P, rhs, bb);
   pack(P, x, xx);
   std::memset(res, 0, sizeof(*res));
   const auto t0 = std::chrono::steady_clock::now();
-  rc = orc::fgmres(P, pt, bb.data(), xx.data(), res, hist);
+  rc = orc::fgmres(P, bb.data(), xx.data(), res, hist);
   res->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   unpack(P, xx, x);
   fill_result(P, res, rc);

@@ -26,7 +26,8 @@ class _Csr(C.Structure):
 class _Problem(C.Structure):
     _fields_ = [("mat", _Csr * _abi.NSLOTS), ("diag", C.c_void_p * _abi.NDIAGS),
                 ("nblocks", C.c_int32), ("nranks_emulated", C.c_int32),
-                ("n", C.c_int64 * _abi.ALFD_MAX_BLOCKS)]
+                ("n", C.c_int64 * _abi.ALFD_MAX_BLOCKS),
+                ("part_offsets", C.c_void_p * _abi.ALFD_MAX_BLOCKS)]
 
 
 def build():
@@ -103,7 +104,7 @@ def dot(x, y):
 class OracleSystem:
     """One block saddle-point system held by host arrays (kept alive here)."""
 
-    def __init__(self, mats: dict, diags: dict, block_sizes, nranks_emulated=1):
+    def __init__(self, mats: dict, diags: dict, block_sizes, nranks_emulated=1, part_offsets=None):
         self._keep = (mats, diags)
         self.block_sizes = list(block_sizes)
         p = _Problem()
@@ -117,6 +118,12 @@ class OracleSystem:
         p.nranks_emulated = nranks_emulated
         for i, n in enumerate(block_sizes):
             p.n[i] = n
+        if part_offsets is not None:
+            for i, o in enumerate(part_offsets):
+                o = np.ascontiguousarray(o, np.int64)
+                assert o.size == nranks_emulated + 1
+                self._keep += (o,)
+                p.part_offsets[i] = o.ctypes.data
         self._p = p
 
     def _check(self, blocks):
@@ -153,11 +160,11 @@ class OracleSystem:
         return rc, x, res, hist[:min(cnt.value, history_cap)].copy()
 
 
-def system_from_problem(pb, nranks_emulated=1) -> OracleSystem:
+def system_from_problem(pb, nranks_emulated=1, part_offsets=None) -> OracleSystem:
     """Wrap a problems.SyntheticProblem: W^-1 = 1/M_ii^2, Mp lumped inverse."""
     mats = {k: pb.mats[k] for k in ("A", "Ct", "C") if k in pb.mats}
     diags = {_abi.INVW: pb.inv_w_diag_squared()}
     if "B" in pb.mats:
         mats.update({k: pb.mats[k] for k in ("B", "Bt", "Mp")})
         diags[_abi.MP_LUMPED_INV] = pb.mp_lumped_inv()
-    return OracleSystem(mats, diags, pb.block_sizes, nranks_emulated)
+    return OracleSystem(mats, diags, pb.block_sizes, nranks_emulated, part_offsets)
