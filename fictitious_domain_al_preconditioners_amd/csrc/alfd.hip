@@ -139,6 +139,10 @@ struct alfd_ctx {
   int64_t pstride = 0;
   double *gather = nullptr;    // multi-rank scalar all-gather buffer
   double *dinv_aug = nullptr, *dA = nullptr, *s_aug = nullptr;
+  double *dinv_a22 = nullptr, *dinv_aug2 = nullptr;   // elliptic: 1/diag(A22_aug), [dinv_aug | dinv_a22]
+  double lam_max[4] = {0, 0, 0, 0};                    // per inner operator kind
+  int64_t wmax = 0;                                    // length of the inner-solve work vectors
+  std::vector<void *> ws_allocs;                       // workspace of the current setup()
   double *w_r = nullptr, *w_z = nullptr, *w_p = nullptr, *w_Ap = nullptr;  // PCG
   double *c_d = nullptr, *c_res = nullptr, *c_tmp = nullptr;               // Chebyshev
   double *t_lam = nullptr;                                                 // invW .* (C x)
@@ -472,33 +476,68 @@ static int read_scalars(alfd_ctx *ctx, int first, int count) {
   } while (0)
 
 // ------------------------------------------------------------- operators
-// y = A x + gamma Ct (invW .* (C x))
-static int aug_apply(alfd_ctx *ctx, const double *x, double *y) {
-  RC(spmv(ctx, ALFD_A, x, y, 0));
-  RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 2, 0.0, ctx->diag[ALFD_INVW]));
-  RC(spmv(ctx, ALFD_CT, ctx->t_lam, y, 1, ctx->cfg.gamma));
-  return ALFD_OK;
+// Inner operators (SPD) the CG runs on:
+//   OP_AUG   y = A x + gamma Ct (invW .* (C x))         stokes...:991-993; A11_aug elliptic...:807
+//   OP_MP    y = Mp x                                   stokes...:929
+//   OP_A22   y = A2 x + gamma2 M (invW .* (M x))        A22_aug, elliptic_interface.cc:810
+//   OP_AUG2  2x2 [[A11_aug, A12_aug],[A21_aug, A22_aug]] on [x0 | pad | x1] (elliptic...:927-929):
+//            s = C x0 - M x1, t = invW .* s, y0 = A x0 + gamma Ct t, y1 = A2 x1 - gamma2 M t
+enum OpKind { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3 };
+
+static inline int64_t op_npad(const alfd_ctx *ctx, int op) {
+  return op == OP_AUG ? pad_chunk(ctx->n[0]) : op == OP_AUG2 ? ctx->off[2] : pad_chunk(ctx->n[1]);
 }
 
-enum OpKind { OP_AUG = 0, OP_MP = 1 };
 static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y) {
-  return op == OP_AUG ? aug_apply(ctx, x, y) : spmv(ctx, ALFD_MP, x, y, 0);
+  const double *w = ctx->diag[ALFD_INVW];
+  switch (op) {
+    case OP_AUG:
+      RC(spmv(ctx, ALFD_A, x, y, 0));
+      RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 2, 0.0, w));
+      return spmv(ctx, ALFD_CT, ctx->t_lam, y, 1, ctx->cfg.gamma);
+    case OP_MP:
+      return spmv(ctx, ALFD_MP, x, y, 0);
+    case OP_A22:
+      RC(spmv(ctx, ALFD_A2, x, y, 0));
+      RC(spmv(ctx, ALFD_M, x, ctx->t_lam, 2, 0.0, w));
+      return spmv(ctx, ALFD_M, ctx->t_lam, y, 1, ctx->cfg.gamma2);
+    default: {
+      const double *x1 = x + ctx->off[1];
+      double *y1 = y + ctx->off[1];
+      const int64_t nlp = pad_chunk(ctx->n[2]);
+      RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 0));
+      RC(spmv(ctx, ALFD_M, x1, ctx->t_lam, 1, -1.0));
+      VEC_LAUNCH(pmul_scale_kernel, nlp, 24, 1.0, w, ctx->t_lam, ctx->t_lam);
+      RC(spmv(ctx, ALFD_A, x, y, 0));
+      RC(spmv(ctx, ALFD_CT, ctx->t_lam, y, 1, ctx->cfg.gamma));
+      RC(spmv(ctx, ALFD_A2, x1, y1, 0));
+      return spmv(ctx, ALFD_M, ctx->t_lam, y1, 1, -ctx->cfg.gamma2);
+    }
+  }
 }
 
-// Chebyshev sweep z = p_k(D^-1 Aug) D^-1 r
-static int cheb_apply(alfd_ctx *ctx, const double *r, double *z, int64_t npad) {
-  const double lmax = ctx->lambda_max, lmin = ctx->lambda_min;
+static const double *op_dinv(const alfd_ctx *ctx, int op) {
+  return op == OP_AUG ? ctx->dinv_aug : op == OP_A22 ? ctx->dinv_a22 : op == OP_AUG2 ? ctx->dinv_aug2
+                                                                                      : ctx->diag[ALFD_MP_LUMPED_INV];
+}
+
+// Chebyshev sweep z = p_k(D^-1 Op) D^-1 r
+static int cheb_apply(alfd_ctx *ctx, int op, const double *r, double *z, int64_t npad) {
+  const double lmax = ctx->lam_max[op], lmin = lmax / ctx->cfg.cheb_eig_ratio;
   const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
   const double sigma = theta / delta;
   double rho = 1.0 / sigma;
   const int k = ctx->cfg.cheb_degree;
-  VEC_LAUNCH(cheb_init_kernel, npad, k > 1 ? 40 : 32, 1.0 / theta, ctx->dinv_aug, r, ctx->c_d, z,
-             ctx->c_res, k > 1 ? 1 : 0);
+  const double *dinv = op_dinv(ctx, op);
+  VEC_LAUNCH(cheb_init_kernel, npad, k > 1 ? 40 : 32, 1.0 / theta, dinv, r, ctx->c_d, z, ctx->c_res,
+             k > 1 ? 1 : 0);
+  // SpMV writes rows only: padding of the product vector must be zero
+  if (k > 1) HIPC(hipMemsetAsync(ctx->c_tmp, 0, npad * sizeof(double), ctx->stream));
   for (int j = 1; j < k; ++j) {
-    RC(aug_apply(ctx, ctx->c_d, ctx->c_tmp));
+    RC(op_apply(ctx, op, ctx->c_d, ctx->c_tmp));
     const double rho_new = 1.0 / (2.0 * sigma - rho);
     const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
-    VEC_LAUNCH(cheb_step_kernel, npad, 64, c1, c2, ctx->dinv_aug, ctx->c_tmp, ctx->c_res, ctx->c_d, z);
+    VEC_LAUNCH(cheb_step_kernel, npad, 64, c1, c2, dinv, ctx->c_tmp, ctx->c_res, ctx->c_d, z);
     rho = rho_new;
   }
   HIPC(hipGetLastError());
@@ -506,18 +545,18 @@ static int cheb_apply(alfd_ctx *ctx, const double *r, double *z, int64_t npad) {
 }
 
 // deal.II SolverCG via inverse_operator (zero initial guess) [EXT]; b and x are
-// padded device vectors of block `blk`.
-static int pcg(alfd_ctx *ctx, int op, int prec, const double *dinv, const alfd_control &ctrl,
-               const double *b, double *x, int blk, int *its_out, State *st_out, double *res_out) {
-  const int64_t npad = pad_chunk(ctx->n[blk]);
+// padded device vectors of the operator's span.
+static int pcg(alfd_ctx *ctx, int op, int prec, const alfd_control &ctrl, const double *b, double *x,
+               int *its_out, State *st_out, double *res_out) {
+  const int64_t npad = op_npad(ctx, op);
   const int64_t nb = npad / kChunk;
+  const double *dinv = op_dinv(ctx, op);
   double *r = ctx->w_r, *z = ctx->w_z, *p = ctx->w_p, *Ap = ctx->w_Ap;
   HIPC(hipMemcpyAsync(r, b, npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   HIPC(hipMemsetAsync(x, 0, npad * sizeof(double), ctx->stream));
-  // SpMV writes rows only: the padding tail of Ap may hold data of a previous,
-  // longer solve and must be zero for the fused r-update / dot kernels.
-  if (npad > ctx->n[blk])
-    HIPC(hipMemsetAsync(Ap + ctx->n[blk], 0, (npad - ctx->n[blk]) * sizeof(double), ctx->stream));
+  // SpMV writes rows only: the padding of Ap may hold data of a previous, longer
+  // solve and must be zero for the fused r-update / dot kernels.
+  HIPC(hipMemsetAsync(Ap, 0, npad * sizeof(double), ctx->stream));
   Control sc{ctrl};
   RC(dot_async(ctx, npad, r, r, S_RR));
   RC(read_scalars(ctx, S_RR, 1));
@@ -534,7 +573,7 @@ static int pcg(alfd_ctx *ctx, int op, int prec, const double *dinv, const alfd_c
       VEC_LAUNCH(jacobi_dot_kernel, npad, 24, dinv, r, z, ctx->partial);
       RC(finish_dots(ctx, nb, 1, 0, FIN_RZ));
     } else {
-      RC(cheb_apply(ctx, r, z, npad));
+      RC(cheb_apply(ctx, op, r, z, npad));
       RC(dot_async(ctx, npad, r, z, 0, FIN_RZ));
     }
     VEC_LAUNCH(p_update_kernel, npad, its == 1 ? 16 : 24, ctx->sc, its == 1 ? 1 : 0, zz, p);
@@ -552,7 +591,17 @@ static int pcg(alfd_ctx *ctx, int op, int prec, const double *dinv, const alfd_c
   return ALFD_OK;
 }
 
-static int inner_status(alfd_ctx *ctx, State st, double res) {
+static int inner_solve(alfd_ctx *ctx, int op, const double *b, double *x) {
+  int its = 0;
+  State st;
+  double res;
+  const bool mp = op == OP_MP;
+  RC(pcg(ctx, op, mp ? (int)ALFD_PREC_JACOBI : ctx->cfg.inner_prec, mp ? ctx->cfg.mp_inner : ctx->cfg.inner, b,
+         x, &its, &st, &res));
+  (mp ? ctx->mp_its : ctx->inner_its) += its;
+  if (ctx->cfg.log_level >= 3 && ctx->rank == 0)
+    std::printf("DEAL:%s:cg::%s step %d value %.17g\n", mp ? "mp" : "aug",
+                st == SUCCESS ? "Convergence" : "Failure", its, res);
   if (st == FAILURE) {
     if (std::isnan(res)) return ctx->err = "inner CG breakdown (NaN)", ALFD_E_BREAKDOWN;
     if (ctx->cfg.on_inner_failure == ALFD_INNER_THROW)
@@ -563,25 +612,7 @@ static int inner_status(alfd_ctx *ctx, State st, double res) {
   return ALFD_OK;
 }
 
-static int inner_solve_aug(alfd_ctx *ctx, const double *b, double *x) {
-  int its = 0;
-  State st;
-  double res;
-  RC(pcg(ctx, OP_AUG, ctx->cfg.inner_prec, ctx->dinv_aug, ctx->cfg.inner, b, x, 0, &its, &st, &res));
-  ctx->inner_its += its;
-  if (ctx->cfg.log_level >= 3 && ctx->rank == 0) std::printf("DEAL:aug:cg::%s step %d value %.17g\n", st == SUCCESS ? "Convergence" : "Failure", its, res);
-  return inner_status(ctx, st, res);
-}
-static int inner_solve_mp(alfd_ctx *ctx, const double *b, double *x) {
-  int its = 0;
-  State st;
-  double res;
-  RC(pcg(ctx, OP_MP, ALFD_PREC_JACOBI, ctx->diag[ALFD_MP_LUMPED_INV], ctx->cfg.mp_inner, b, x, 1, &its,
-         &st, &res));
-  ctx->mp_its += its;
-  if (ctx->cfg.log_level >= 3 && ctx->rank == 0) std::printf("DEAL:mp:cg::%s step %d value %.17g\n", st == SUCCESS ? "Convergence" : "Failure", its, res);
-  return inner_status(ctx, st, res);
-}
+static inline bool is_elliptic(int v) { return v == ALFD_AL_ELL_IDEAL || v == ALFD_AL_ELL_MODIFIED; }
 
 // Preconditioner vmult on padded device block vectors.
 static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
@@ -589,22 +620,21 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
   const alfd_config &c = ctx->cfg;
   const double *w = ctx->diag[ALFD_INVW];
   const int64_t *off = ctx->off;
+  const int64_t n0p = pad_chunk(ctx->n[0]), n1p = pad_chunk(ctx->n[1]), n2p = pad_chunk(ctx->n[2]);
   if (c.variant == ALFD_AL2) {
     // augmented_lagrangian_preconditioner.h:28-34
-    const int64_t n1p = pad_chunk(ctx->n[1]), n0p = pad_chunk(ctx->n[0]);
     VEC_LAUNCH(pmul_scale_kernel, n1p, 24, -c.gamma, w, u + off[1], v + off[1]);
     HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
                         ctx->stream));
     RC(spmv(ctx, ALFD_CT, v + off[1], ctx->rhs_tmp, 1, -1.0));
-    return inner_solve_aug(ctx, ctx->rhs_tmp, v + off[0]);
+    return inner_solve(ctx, OP_AUG, ctx->rhs_tmp, v + off[0]);
   }
   if (c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG) {
     // :62-70 (block triangular) / :95-103 (block diagonal SPD)
     const bool tri = c.variant == ALFD_AL_STOKES;
     const double sgn = tri ? -1.0 : 1.0;
-    const int64_t n0p = pad_chunk(ctx->n[0]), n1p = pad_chunk(ctx->n[1]), n2p = pad_chunk(ctx->n[2]);
     VEC_LAUNCH(pmul_scale_kernel, n2p, 24, sgn * c.gamma, w, u + off[2], v + off[2]);
-    RC(inner_solve_mp(ctx, u + off[1], ctx->q_tmp));
+    RC(inner_solve(ctx, OP_MP, u + off[1], ctx->q_tmp));
     VEC_LAUNCH(scale_copy_kernel, n1p, 16, sgn * c.gamma_grad_div, ctx->q_tmp, v + off[1]);
     HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
                         ctx->stream));
@@ -612,7 +642,29 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
       RC(spmv(ctx, ALFD_BT, v + off[1], ctx->rhs_tmp, 1, -1.0));
       RC(spmv(ctx, ALFD_CT, v + off[2], ctx->rhs_tmp, 1, -1.0));
     }
-    return inner_solve_aug(ctx, ctx->rhs_tmp, v + off[0]);
+    return inner_solve(ctx, OP_AUG, ctx->rhs_tmp, v + off[0]);
+  }
+  if (c.variant == ALFD_AL_ELL_MODIFIED) {
+    // BlockTriangularALPreconditionerModified::vmult, ...preconditioner.h:225-228
+    double *d0 = v + off[0], *d1 = v + off[1], *d2 = v + off[2];
+    VEC_LAUNCH(pmul_scale_kernel, n2p, 24, -c.gamma, w, u + off[2], d2);        // d2 = -gamma invW lambda
+    HIPC(hipMemcpyAsync(ctx->q_tmp, u + off[1], n1p * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    RC(spmv(ctx, ALFD_M, d2, ctx->q_tmp, 1, 1.0));                              // u2 + M d2
+    RC(inner_solve(ctx, OP_A22, ctx->q_tmp, d1));                               // d1 = A22_inv (...)
+    RC(spmv(ctx, ALFD_M, d1, ctx->t_lam, 2, 0.0, w));                           // t = invW M d1
+    HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
+                        ctx->stream));
+    RC(spmv(ctx, ALFD_CT, ctx->t_lam, ctx->rhs_tmp, 1, c.gamma));               // u + gamma Ct t
+    RC(spmv(ctx, ALFD_CT, d2, ctx->rhs_tmp, 1, -1.0));                          //   - Ct d2
+    return inner_solve(ctx, OP_AUG, ctx->rhs_tmp, d0);                          // d0 = A11_inv (...)
+  }
+  if (c.variant == ALFD_AL_ELL_IDEAL) {
+    // BlockTriangularALPreconditioner::vmult, ...preconditioner.h:130-156
+    VEC_LAUNCH(pmul_scale_kernel, n2p, 24, -c.gamma, w, u + off[2], v + off[2]);
+    HIPC(hipMemcpyAsync(ctx->rhs_tmp, u, off[2] * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    RC(spmv(ctx, ALFD_CT, v + off[2], ctx->rhs_tmp, 1, -1.0));                  // u0 - Ct v2
+    RC(spmv(ctx, ALFD_M, v + off[2], ctx->rhs_tmp + off[1], 1, 1.0));           // u1 + M v2
+    return inner_solve(ctx, OP_AUG2, ctx->rhs_tmp, v);                          // [v0;v1] = Aug_inv (...)
   }
   return ctx->err = "preconditioner variant not implemented yet", ALFD_E_UNSUPPORTED;
 }
@@ -622,11 +674,12 @@ static int system_apply(alfd_ctx *ctx, const double *x, double *y) {
   const alfd_config &c = ctx->cfg;
   const int64_t *off = ctx->off;
   const int last = ctx->nblocks - 1;
+  const double *w = ctx->diag[ALFD_INVW];
   if (c.variant == ALFD_AL2 || c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG) {
     const double *x0 = x + off[0];
     double *y0 = y + off[0];
     RC(spmv(ctx, ALFD_A, x0, y0, 0));
-    RC(spmv(ctx, ALFD_C, x0, y + off[last], 3, 0.0, ctx->diag[ALFD_INVW], ctx->t_lam));
+    RC(spmv(ctx, ALFD_C, x0, y + off[last], 3, 0.0, w, ctx->t_lam));
     RC(spmv(ctx, ALFD_CT, ctx->t_lam, y0, 1, c.gamma));
     if (ctx->nblocks == 3) {
       RC(spmv(ctx, ALFD_BT, x + off[1], y0, 1, 1.0));
@@ -634,6 +687,20 @@ static int system_apply(alfd_ctx *ctx, const double *x, double *y) {
     }
     RC(spmv(ctx, ALFD_CT, x + off[last], y0, 1, 1.0));
     return ALFD_OK;
+  }
+  if (is_elliptic(c.variant)) {
+    // elliptic_interface.cc:810-819
+    const double *x0 = x + off[0], *x1 = x + off[1], *x2 = x + off[2];
+    double *y0 = y + off[0], *y1 = y + off[1], *y2 = y + off[2];
+    RC(spmv(ctx, ALFD_C, x0, y2, 0));
+    RC(spmv(ctx, ALFD_M, x1, y2, 1, -1.0));                                     // y2 = C x0 - M x1
+    VEC_LAUNCH(pmul_scale_kernel, pad_chunk(ctx->n[2]), 24, 1.0, w, y2, ctx->t_lam);
+    RC(spmv(ctx, ALFD_A, x0, y0, 0));
+    RC(spmv(ctx, ALFD_CT, ctx->t_lam, y0, 1, c.gamma));
+    RC(spmv(ctx, ALFD_CT, x2, y0, 1, 1.0));
+    RC(spmv(ctx, ALFD_A2, x1, y1, 0));
+    RC(spmv(ctx, ALFD_M, ctx->t_lam, y1, 1, -c.gamma2));
+    return spmv(ctx, ALFD_M, x2, y1, 1, -1.0);
   }
   return ctx->err = "system operator variant not implemented yet", ALFD_E_UNSUPPORTED;
 }
@@ -1053,14 +1120,101 @@ static int upload_transpose(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncol
 
 static int nblocks_of(int variant) { return variant == ALFD_AL2 || variant == ALFD_RATIONAL ? 2 : 3; }
 
+static int ws_alloc_zero(alfd_ctx *ctx, double **p, int64_t count) {
+  void *q = nullptr;
+  HIPC(hipMalloc(&q, std::max<int64_t>(count, 1) * sizeof(double)));
+  ctx->ws_allocs.push_back(q);
+  *p = static_cast<double *>(q);
+  HIPC(hipMemsetAsync(q, 0, std::max<int64_t>(count, 1) * sizeof(double), ctx->stream));
+  return ALFD_OK;
+}
+
+// dinv = 1 / (diag(Adiag) + g * sum_k w_k R_ik^2): the diagonal of Adiag + g R diag(w) R^T
+static int diag_plus(alfd_ctx *ctx, int slot_diag, int slot_rows, double g, int64_t n, double *dinv) {
+  const DevCsr &A = ctx->mat[slot_diag];
+  DevCsr &R = ctx->mat[slot_rows];
+  HIPC(hipMemsetAsync(ctx->dA, 0, pad_chunk(n) * sizeof(double), ctx->stream));
+  HIPC(hipMemsetAsync(ctx->s_aug, 0, pad_chunk(n) * sizeof(double), ctx->stream));
+  const int grid = grid_for_rows(A.nrows, A.L);
+#define ALFD_DIAG(LL)                                                                                   \
+  hipLaunchKernelGGL((extract_diag_kernel<LL>), dim3(grid), dim3(kBlock), 0, ctx->stream, A.nrows, A.rp, \
+                     A.col, A.val, ctx->dA)
+  switch (A.L) {
+    case 4: ALFD_DIAG(4); break;
+    case 8: ALFD_DIAG(8); break;
+    case 16: ALFD_DIAG(16); break;
+    case 32: ALFD_DIAG(32); break;
+    default: ALFD_DIAG(64); break;
+  }
+#undef ALFD_DIAG
+  // a rank with no rows of R of its own may still own W entries its peers need
+  if (ctx->nranks > 1 && (ctx->local || R.n_halo > 0 || R.send_off.back() > 0))
+    RC(halo_exchange(ctx, R, ctx->diag[ALFD_INVW]));
+  if (R.n_list > 0)
+    hipLaunchKernelGGL(aug_diag_rows_kernel, dim3((unsigned)((R.n_list + 255) / 256)), dim3(256), 0,
+                       ctx->stream, R.n_list, R.rp, R.col, R.val, R.sparse ? R.rows : nullptr,
+                       ctx->diag[ALFD_INVW], R.halo, R.n_local_cols, ctx->s_aug);
+  hipLaunchKernelGGL(aug_diag_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                     g, ctx->dA, ctx->s_aug, dinv);
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+// lambda_max(D^-1 Op) by power iteration from the integer-hash start vector
+static int power_iteration(alfd_ctx *ctx, int op) {
+  const alfd_config &c = ctx->cfg;
+  const int64_t npad = op_npad(ctx, op);
+  double *v = ctx->w_p, *wv = ctx->w_Ap;
+  HIPC(hipMemsetAsync(v, 0, npad * sizeof(double), ctx->stream));
+  HIPC(hipMemsetAsync(wv, 0, npad * sizeof(double), ctx->stream));
+  auto fill = [&](int blk, double *dst) {
+    const int64_t goff = ctx->nranks > 1 ? ctx->part[blk][ctx->rank] : 0;
+    hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((ctx->n[blk] + 255) / 256)), dim3(256), 0,
+                       ctx->stream, ctx->n[blk], goff, dst);
+  };
+  if (op == OP_AUG2) {
+    fill(0, v);
+    fill(1, v + ctx->off[1]);
+  } else {
+    fill(op == OP_AUG ? 0 : 1, v);
+  }
+  double lam = 0;
+  for (int it = 0; it < c.cheb_power_its; ++it) {
+    RC(dot_async(ctx, npad, v, v, S_TMP));
+    RC(read_scalars(ctx, S_TMP, 1));
+    const double nv = std::sqrt(ctx->sc_host[S_TMP]);
+    VEC_LAUNCH(scale_kernel, npad, 16, (const double *)nullptr, 0, 0, 1.0 / nv, v);
+    RC(op_apply(ctx, op, v, wv));
+    VEC_LAUNCH(pmul_scale_kernel, npad, 24, 1.0, op_dinv(ctx, op), wv, wv);
+    RC(dot_async(ctx, npad, wv, wv, S_TMP));
+    RC(read_scalars(ctx, S_TMP, 1));
+    lam = std::sqrt(ctx->sc_host[S_TMP]);
+    std::swap(v, wv);
+  }
+  ctx->lam_max[op] = lam * c.cheb_safety;
+  HIPC(hipMemsetAsync(ctx->w_p, 0, ctx->wmax * sizeof(double), ctx->stream));
+  HIPC(hipMemsetAsync(ctx->w_Ap, 0, ctx->wmax * sizeof(double), ctx->stream));
+  return ALFD_OK;
+}
+
 static int setup(alfd_ctx *ctx) {
   if (!ctx->configured) return ctx->err = "alfd_configure not called", ALFD_E_NOT_SETUP;
   const alfd_config &c = ctx->cfg;
-  if (c.variant != ALFD_AL2 && c.variant != ALFD_AL_STOKES && c.variant != ALFD_AL_STOKES_DIAG)
-    return ctx->err = "variant not implemented yet", ALFD_E_UNSUPPORTED;
+  if (c.variant == ALFD_RATIONAL) return ctx->err = "variant not implemented yet", ALFD_E_UNSUPPORTED;
   if (c.restart < 1 || c.restart > kMaxBasis - 1) return ctx->err = "restart out of range", ALFD_E_INVALID;
-  if (!c.grad_div_in_A && c.variant != ALFD_AL2)
+  const bool ell = is_elliptic(c.variant);
+  if (!c.grad_div_in_A && (c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG))
     return ctx->err = "grad_div_in_A = 0 (nested Bt Mp^-1 B in Aug) not implemented", ALFD_E_UNSUPPORTED;
+  if (c.inner_prec == ALFD_PREC_CHEBYSHEV &&
+      (c.cheb_degree < 1 || c.cheb_power_its < 1 || !(c.cheb_eig_ratio > 1.0)))
+    return ctx->err = "bad Chebyshev parameters", ALFD_E_INVALID;
+  // parameter sanity the reference asserts (elliptic_interface.cc:874-884, 912-920)
+  if (c.variant == ALFD_AL_ELL_MODIFIED && c.gamma2 > 20.0)
+    return ctx->err = "gamma_AL_immersed is too large for modified AL preconditioner", ALFD_E_INVALID;
+  if (c.variant == ALFD_AL_ELL_MODIFIED && std::fabs(c.gamma2 - c.gamma) <= 1e-1)
+    return ctx->err = "modified AL preconditioner: gamma_1 and gamma_2 should not be too close", ALFD_E_INVALID;
+  if (c.variant == ALFD_AL_ELL_IDEAL && std::fabs(c.gamma - c.gamma2) >= 1e-12)
+    return ctx->err = "ideal AL preconditioner: gamma must be identical", ALFD_E_INVALID;
   ctx->nblocks = nblocks_of(c.variant);
   const int last = ctx->nblocks - 1;
   if (!ctx->mat[ALFD_A].present || !ctx->mat[ALFD_CT].present || !ctx->mat[ALFD_C].present ||
@@ -1068,7 +1222,13 @@ static int setup(alfd_ctx *ctx) {
     return ctx->err = "A, CT (and C) and INVW must be set", ALFD_E_NOT_SETUP;
   ctx->n[0] = ctx->mat[ALFD_A].nrows;
   ctx->n[last] = ctx->mat[ALFD_C].nrows;
-  if (ctx->nblocks == 3) {
+  if (ell) {
+    if (!ctx->mat[ALFD_A2].present || !ctx->mat[ALFD_M].present)
+      return ctx->err = "A2 and M must be set for the elliptic-interface variants", ALFD_E_NOT_SETUP;
+    ctx->n[1] = ctx->mat[ALFD_A2].nrows;
+    if (ctx->n[1] != ctx->n[2] || ctx->mat[ALFD_M].nrows != ctx->n[1])
+      return ctx->err = "elliptic interface: blocks 1 and 2 must have the same size", ALFD_E_INVALID;
+  } else if (ctx->nblocks == 3) {
     if (!ctx->mat[ALFD_BT].present || !ctx->mat[ALFD_B].present || !ctx->mat[ALFD_MP].present ||
         !ctx->diag[ALFD_MP_LUMPED_INV])
       return ctx->err = "BT, B, MP and MP_LUMPED_INV must be set for the Stokes variants", ALFD_E_NOT_SETUP;
@@ -1081,86 +1241,60 @@ static int setup(alfd_ctx *ctx) {
     ctx->off[b + 1] = ctx->off[b] + pad_chunk(ctx->n[b]);
     ctx->nmax = std::max(ctx->nmax, pad_chunk(ctx->n[b]));
   }
+  // release the workspace of a previous setup()
+  HIPC(hipStreamSynchronize(ctx->stream));
+  for (void *p : ctx->ws_allocs) hipFree(p);
+  ctx->ws_allocs.clear();
+  if (ctx->sc_host) hipHostFree(ctx->sc_host), ctx->sc_host = nullptr;
   const int64_t N = ctx->ntot(), n0p = pad_chunk(ctx->n[0]);
+  ctx->wmax = c.variant == ALFD_AL_ELL_IDEAL ? ctx->off[2] : ctx->nmax;
+  const int64_t wm = ctx->wmax;
   ctx->pstride = N / kChunk + 1;
-  RC(dev_alloc_zero(ctx, &ctx->sc, kNumScalars));
+  RC(ws_alloc_zero(ctx, &ctx->sc, kNumScalars));
   HIPC(hipHostMalloc((void **)&ctx->sc_host, kNumScalars * sizeof(double)));
-  RC(dev_alloc_zero(ctx, &ctx->partial, (int64_t)(kMaxBasis + 2) * ctx->pstride));
-  RC(dev_alloc_zero(ctx, &ctx->gather, (int64_t)ctx->nranks * (kMaxBasis + 2)));
-  RC(dev_alloc_zero(ctx, &ctx->dinv_aug, n0p));
-  RC(dev_alloc_zero(ctx, &ctx->dA, n0p));
-  RC(dev_alloc_zero(ctx, &ctx->s_aug, n0p));
-  RC(dev_alloc_zero(ctx, &ctx->w_r, ctx->nmax));
-  RC(dev_alloc_zero(ctx, &ctx->w_z, ctx->nmax));
-  RC(dev_alloc_zero(ctx, &ctx->w_p, ctx->nmax));
-  RC(dev_alloc_zero(ctx, &ctx->w_Ap, ctx->nmax));
-  RC(dev_alloc_zero(ctx, &ctx->c_d, n0p));
-  RC(dev_alloc_zero(ctx, &ctx->c_res, n0p));
-  RC(dev_alloc_zero(ctx, &ctx->c_tmp, n0p));
-  RC(dev_alloc_zero(ctx, &ctx->t_lam, pad_chunk(ctx->n[last])));
-  RC(dev_alloc_zero(ctx, &ctx->q_tmp, ctx->nmax));
-  RC(dev_alloc_zero(ctx, &ctx->rhs_tmp, n0p));
-  RC(dev_alloc_zero(ctx, &ctx->V, (int64_t)(c.restart + 1) * N));
-  RC(dev_alloc_zero(ctx, &ctx->Z, (int64_t)c.restart * N));
-  RC(dev_alloc_zero(ctx, &ctx->xb, N));
-  RC(dev_alloc_zero(ctx, &ctx->bb, N));
-  RC(dev_alloc_zero(ctx, &ctx->io, N));
-  // diag(Aug) = diag(A) + gamma * sum_k w_k Ct_ik^2
-  {
-    const DevCsr &A = ctx->mat[ALFD_A];
-    const DevCsr &Ct = ctx->mat[ALFD_CT];
-    const int grid = grid_for_rows(A.nrows, A.L);
-#define ALFD_DIAG(LL)                                                                                   \
-  hipLaunchKernelGGL((extract_diag_kernel<LL>), dim3(grid), dim3(kBlock), 0, ctx->stream, A.nrows, A.rp, \
-                     A.col, A.val, ctx->dA)
-    switch (A.L) {
-      case 4: ALFD_DIAG(4); break;
-      case 8: ALFD_DIAG(8); break;
-      case 16: ALFD_DIAG(16); break;
-      case 32: ALFD_DIAG(32); break;
-      default: ALFD_DIAG(64); break;
+  RC(ws_alloc_zero(ctx, &ctx->partial, (int64_t)(kMaxBasis + 2) * ctx->pstride));
+  RC(ws_alloc_zero(ctx, &ctx->gather, (int64_t)ctx->nranks * (kMaxBasis + 2)));
+  RC(ws_alloc_zero(ctx, &ctx->dinv_aug, n0p));
+  RC(ws_alloc_zero(ctx, &ctx->dA, ctx->nmax));
+  RC(ws_alloc_zero(ctx, &ctx->s_aug, ctx->nmax));
+  RC(ws_alloc_zero(ctx, &ctx->w_r, wm));
+  RC(ws_alloc_zero(ctx, &ctx->w_z, wm));
+  RC(ws_alloc_zero(ctx, &ctx->w_p, wm));
+  RC(ws_alloc_zero(ctx, &ctx->w_Ap, wm));
+  RC(ws_alloc_zero(ctx, &ctx->c_d, wm));
+  RC(ws_alloc_zero(ctx, &ctx->c_res, wm));
+  RC(ws_alloc_zero(ctx, &ctx->c_tmp, wm));
+  RC(ws_alloc_zero(ctx, &ctx->t_lam, pad_chunk(ctx->n[last])));
+  RC(ws_alloc_zero(ctx, &ctx->q_tmp, ctx->nmax));
+  RC(ws_alloc_zero(ctx, &ctx->rhs_tmp, std::max(n0p, wm)));
+  RC(ws_alloc_zero(ctx, &ctx->V, (int64_t)(c.restart + 1) * N));
+  RC(ws_alloc_zero(ctx, &ctx->Z, (int64_t)c.restart * N));
+  RC(ws_alloc_zero(ctx, &ctx->xb, N));
+  RC(ws_alloc_zero(ctx, &ctx->bb, N));
+  RC(ws_alloc_zero(ctx, &ctx->io, N));
+  for (int k = 0; k < 4; ++k) ctx->lam_max[k] = 0;
+  // diag(Aug) = diag(A) + gamma sum_k w_k Ct_ik^2 (no product matrix is formed)
+  RC(diag_plus(ctx, ALFD_A, ALFD_CT, c.gamma, ctx->n[0], ctx->dinv_aug));
+  const bool cheb = c.inner_prec == ALFD_PREC_CHEBYSHEV;
+  if (ell) {
+    // diag(A22_aug) = diag(A2) + gamma2 sum_k w_k M_ik^2
+    RC(ws_alloc_zero(ctx, &ctx->dinv_a22, pad_chunk(ctx->n[1])));
+    RC(diag_plus(ctx, ALFD_A2, ALFD_M, c.gamma2, ctx->n[1], ctx->dinv_a22));
+    if (c.variant == ALFD_AL_ELL_IDEAL) {
+      RC(ws_alloc_zero(ctx, &ctx->dinv_aug2, ctx->off[2]));
+      HIPC(hipMemcpyAsync(ctx->dinv_aug2, ctx->dinv_aug, n0p * sizeof(double), hipMemcpyDeviceToDevice,
+                          ctx->stream));
+      HIPC(hipMemcpyAsync(ctx->dinv_aug2 + ctx->off[1], ctx->dinv_a22, pad_chunk(ctx->n[1]) * sizeof(double),
+                          hipMemcpyDeviceToDevice, ctx->stream));
+      if (cheb) RC(power_iteration(ctx, OP_AUG2));
+    } else if (cheb) {
+      RC(power_iteration(ctx, OP_AUG));
+      RC(power_iteration(ctx, OP_A22));
     }
-#undef ALFD_DIAG
-    // a rank with no coupling rows of its own may still own W entries its peers need
-    if (ctx->nranks > 1 && (ctx->local || Ct.n_halo > 0 || Ct.send_off.back() > 0)) {
-      DevCsr &Ctm = ctx->mat[ALFD_CT];
-      RC(halo_exchange(ctx, Ctm, ctx->diag[ALFD_INVW]));
-    }
-    if (Ct.n_list > 0) {
-      hipLaunchKernelGGL(aug_diag_rows_kernel, dim3((unsigned)((Ct.n_list + 255) / 256)), dim3(256), 0,
-                         ctx->stream, Ct.n_list, Ct.rp, Ct.col, Ct.val, Ct.sparse ? Ct.rows : nullptr,
-                         ctx->diag[ALFD_INVW], Ct.halo, Ct.n_local_cols, ctx->s_aug);
-    }
-    hipLaunchKernelGGL(aug_diag_finish_kernel, dim3((unsigned)((ctx->n[0] + 255) / 256)), dim3(256), 0,
-                       ctx->stream, ctx->n[0], c.gamma, ctx->dA, ctx->s_aug, ctx->dinv_aug);
-    HIPC(hipGetLastError());
+  } else if (cheb) {
+    RC(power_iteration(ctx, OP_AUG));
   }
-  ctx->lambda_max = ctx->lambda_min = 0;
-  if (c.inner_prec == ALFD_PREC_CHEBYSHEV) {
-    if (c.cheb_degree < 1 || c.cheb_power_its < 1 || !(c.cheb_eig_ratio > 1.0))
-      return ctx->err = "bad Chebyshev parameters", ALFD_E_INVALID;
-    double *v = ctx->w_p, *wv = ctx->w_Ap;
-    const int64_t goff = ctx->nranks > 1 ? ctx->part[0][ctx->rank] : 0;
-    hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((ctx->n[0] + 255) / 256)), dim3(256), 0,
-                       ctx->stream, ctx->n[0], goff, v);
-    double lam = 0;
-    for (int it = 0; it < c.cheb_power_its; ++it) {
-      RC(dot_async(ctx, n0p, v, v, S_TMP));
-      RC(read_scalars(ctx, S_TMP, 1));
-      const double nv = std::sqrt(ctx->sc_host[S_TMP]);
-      VEC_LAUNCH(scale_kernel, n0p, 16, (const double *)nullptr, 0, 0, 1.0 / nv, v);
-      RC(aug_apply(ctx, v, wv));
-      VEC_LAUNCH(pmul_scale_kernel, n0p, 24, 1.0, ctx->dinv_aug, wv, wv);
-      RC(dot_async(ctx, n0p, wv, wv, S_TMP));
-      RC(read_scalars(ctx, S_TMP, 1));
-      lam = std::sqrt(ctx->sc_host[S_TMP]);
-      std::swap(v, wv);
-    }
-    ctx->lambda_max = lam * c.cheb_safety;
-    ctx->lambda_min = ctx->lambda_max / c.cheb_eig_ratio;
-    HIPC(hipMemsetAsync(ctx->w_p, 0, ctx->nmax * sizeof(double), ctx->stream));
-    HIPC(hipMemsetAsync(ctx->w_Ap, 0, ctx->nmax * sizeof(double), ctx->stream));
-  }
+  ctx->lambda_max = ctx->lam_max[c.variant == ALFD_AL_ELL_IDEAL ? OP_AUG2 : OP_AUG];
   HIPC(hipStreamSynchronize(ctx->stream));
   ctx->is_setup = true;
   return ALFD_OK;
@@ -1257,6 +1391,7 @@ int alfd_destroy(alfd_ctx_t ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   flush_timers(ctx);
+  for (void *p : ctx->ws_allocs) hipFree(p);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->sc_host) hipHostFree(ctx->sc_host);
   if (ctx->nccl) ncclCommDestroy(ctx->nccl);

@@ -220,6 +220,13 @@ struct Params {
   int coupling_nq = 3;
   double body_force[3] = {0, 0, 0};
   double embedded_value[3] = {1, 0, 0};
+  // immersed_kind 1: the immersed domain is a BOX meshed with imm_cells^dim Q1
+  // cells (elliptic_interface: Omega_2 = [-0.14, 0.47]^2, parameters_modified.prm:53-56);
+  // the coupling is then a VOLUME integral over Omega_2 and A2 = beta2 * stiffness.
+  int immersed_kind = 0;
+  double imm_lo = 0.25, imm_hi = 0.75;
+  int imm_cells = 8;
+  double beta2 = 0.0;
   // row ranges of this process (multi-GPU row partition); -1 = everything.
   // u/p ranges are in NODES (z-slabs of the lexicographic numbering), l in dofs.
   int64_t u_node0 = -1, u_node1 = -1, p_node0 = -1, p_node1 = -1, l0 = -1, l1 = -1;
@@ -537,6 +544,29 @@ Immersed make_cubed_sphere(const Params &P) {
   return im;
 }
 
+// 2-D box [lo,hi]^2 meshed with m x m bilinear cells (nodes lexicographic, x fastest).
+Immersed make_box_2d(const Params &P) {
+  Immersed im;
+  im.cell_nodes = 4;
+  const int m = P.imm_cells;
+  const double h = (P.imm_hi - P.imm_lo) / m;
+  for (int j = 0; j <= m; ++j)
+    for (int i = 0; i <= m; ++i) {
+      im.xyz.push_back(P.imm_lo + i * h);
+      im.xyz.push_back(P.imm_lo + j * h);
+      im.xyz.push_back(0.0);
+    }
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < m; ++i) {
+      const int n0 = j * (m + 1) + i;
+      im.cells.push_back(n0);
+      im.cells.push_back(n0 + 1);
+      im.cells.push_back(n0 + m + 2);
+      im.cells.push_back(n0 + m + 1);
+    }
+  return im;
+}
+
 // One quadrature point on an immersed cell.
 struct QPoint {
   const int *cn;      // cell node ids
@@ -612,7 +642,7 @@ void immersed_quadrature(const Immersed &im, int nq, F &&f) {
 
 void build_immersed(const Params &P, const Grid &g, Problem &pb) {
   const int dim = g.dim, nc = P.ncomp;
-  Immersed im = (dim == 2) ? make_circle(P) : make_cubed_sphere(P);
+  Immersed im = P.immersed_kind == 1 ? make_box_2d(P) : (dim == 2) ? make_circle(P) : make_cubed_sphere(P);
   const int64_t nl = im.nnodes();
   std::vector<Triplet> tc, tm, tk;
   std::vector<double> gint(nl, 0.0);  // int chi_k
@@ -686,6 +716,17 @@ void build_immersed(const Params &P, const Grid &g, Problem &pb) {
   for (int64_t k = 0; k < nl; ++k)
     for (int b = 0; b < nc; ++b) gv[k * nc + b] = P.embedded_value[b] * gint[k];
   pb.vecs["n_lambda_global"] = {(double)(nl * nc)};
+  if (P.immersed_kind == 1) {
+    // elliptic_interface: A2 = (beta_2 - beta_1) (grad, grad) on Omega_2 (elliptic...:681),
+    // f2 = int (f_2 - f) chi_k with f_2 - f = 1 (parameters_modified.prm:25-29)
+    Csr A2 = Kx;
+    for (auto &v : A2.val) v *= P.beta2;
+    pb.mats["A2"] = std::move(A2);
+    std::vector<double> f2(nl * nc);
+    for (int64_t k = 0; k < nl; ++k)
+      for (int b = 0; b < nc; ++b) f2[k * nc + b] = gint[k];
+    pb.vecs["f2"] = std::move(f2);
+  }
   if (P.u_node0 >= 0) {
     pb.mats["Ct"] = csr_slice_rows(Ct, P.u_node0 * nc, P.u_node1 * nc);
     pb.mats["C"] = csr_slice_rows(C, P.l0, P.l1);
@@ -731,6 +772,8 @@ bool generate(Problem &pb) {
     return pb.err = "stokes needs degree 2 and ncomp == dim", false;
   if (P.n_cells < 2) return pb.err = "n_cells must be >= 2", false;
   if (P.coupling_nq < 1 || P.coupling_nq > 5) return pb.err = "coupling_nq in 1..5", false;
+  if (P.immersed_kind == 1 && (P.dim != 2 || P.ncomp != 1 || P.imm_cells < 1 || !(P.imm_hi > P.imm_lo)))
+    return pb.err = "box-immersed mode needs dim 2, ncomp 1, imm_cells >= 1, imm_hi > imm_lo", false;
   Grid g;
   g.dim = P.dim;
   g.p = P.degree;
@@ -801,6 +844,8 @@ struct alfd_synth_params {
   double body_force[3];
   double embedded_value[3];
   int64_t u_node0, u_node1, p_node0, p_node1, l0, l1;
+  int32_t immersed_kind, imm_cells;
+  double imm_lo, imm_hi, beta2;
 };
 
 void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
@@ -830,6 +875,11 @@ void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
   P.p_node1 = sp->p_node1;
   P.l0 = sp->l0;
   P.l1 = sp->l1;
+  P.immersed_kind = sp->immersed_kind;
+  P.imm_cells = sp->imm_cells;
+  P.imm_lo = sp->imm_lo;
+  P.imm_hi = sp->imm_hi;
+  P.beta2 = sp->beta2;
   if (!generate(*pb)) {
     if (err && errlen > 0) std::snprintf(err, errlen, "%s", pb->err.c_str());
     delete pb;

@@ -152,6 +152,7 @@ def config_from_prm(tree: dict) -> tuple[_abi.Config, dict]:
             raise ValueError("Parameter gamma is probably too small for classical AL preconditioner")
         if not modified and abs(cfg.gamma - cfg.gamma2) >= 1e-12:
             raise ValueError("In the ideal case, gamma must be identical")
-        info["unsupported"].append("elliptic_interface variants are not implemented on the GPU yet")
+        if not info["diagonal_W"]:
+            info["unsupported"].append("Use diagonal inverse = false (UMFPACK M^-1 M^-1)")
         return cfg, info
     raise ValueError("no known driver section in this .prm")

@@ -32,6 +32,8 @@ class _Params(C.Structure):
         ("body_force", C.c_double * 3), ("embedded_value", C.c_double * 3),
         ("u_node0", C.c_int64), ("u_node1", C.c_int64), ("p_node0", C.c_int64), ("p_node1", C.c_int64),
         ("l0", C.c_int64), ("l1", C.c_int64),
+        ("immersed_kind", C.c_int32), ("imm_cells", C.c_int32),
+        ("imm_lo", C.c_double), ("imm_hi", C.c_double), ("beta2", C.c_double),
     ]
 
 
@@ -145,6 +147,8 @@ class SyntheticProblem:
         """LOCAL block sizes (== global when the problem is not partitioned)."""
         n_u = self.mats["A"].nrows
         n_l = self.mats["C"].nrows
+        if "A2" in self.mats:       # elliptic interface: [u (background), u2 (immersed), lambda]
+            return [n_u, n_l, n_l]
         if "B" in self.mats:
             return [n_u, self.mats["B"].nrows, n_l]
         return [n_u, n_l]
@@ -162,6 +166,12 @@ class SyntheticProblem:
         d = self.mats["M"].diagonal(self.row_ranges[4] if self.row_ranges else 0)
         return 1.0 / (d * d)
 
+    def inv_w_diag_of_mass_squared(self) -> np.ndarray:
+        """W^-1 = 1 / (M M)_ii, the true diagonal of M^2 (utilities.h:348-374,
+        elliptic_interface.cc:726)."""
+        m = self.mats["M"].to_scipy()
+        return 1.0 / np.asarray(m.multiply(m.T).sum(axis=1)).ravel()
+
     def mp_lumped_inv(self) -> np.ndarray:
         """1 / (Mp 1)_i  (stokes_immersed_boundary.cc:946-954)."""
         mp = self.mats["Mp"]
@@ -171,8 +181,10 @@ class SyntheticProblem:
 def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False, grad_div=False,
              gamma_grad_div=0.0, beta=1.0, center=(0.5, 0.5, 0.5), radius=0.2, immersed_refine=3,
              coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0),
-             row_ranges=None) -> SyntheticProblem:
-    """row_ranges = (u_node0, u_node1, p_node0, p_node1, l0, l1): generate only this
+             row_ranges=None, immersed_box=None, beta2=0.0) -> SyntheticProblem:
+    """immersed_box = (lo, hi, cells): the immersed domain is the 2-D box [lo,hi]^2
+    with cells^2 Q1 cells (volume coupling, elliptic_interface); beta2 scales "A2".
+    row_ranges = (u_node0, u_node1, p_node0, p_node1, l0, l1): generate only this
     rank's rows (node ranges for the background spaces, dof range for the
     multiplier); column indices stay global.  None = the whole problem."""
     lib = _load()
@@ -188,6 +200,9 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     p.radius, p.immersed_refine, p.coupling_nq = radius, immersed_refine, coupling_nq
     rr = tuple(int(v) for v in row_ranges) if row_ranges is not None else (-1,) * 6
     p.u_node0, p.u_node1, p.p_node0, p.p_node1, p.l0, p.l1 = rr
+    if immersed_box is not None:
+        p.immersed_kind, p.imm_lo, p.imm_hi, p.imm_cells = 1, float(immersed_box[0]), float(immersed_box[1]), int(immersed_box[2])
+        p.beta2 = beta2
     err = C.create_string_buffer(256)
     h = lib.alfd_synth_generate(C.byref(p), err, 256)
     if not h:
@@ -198,7 +213,7 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     owner = _NativeHandle(h)
     pb = SyntheticProblem(params=params, _handle=owner,
                           row_ranges=rr if row_ranges is not None else None)
-    for name in ("A", "B", "Bt", "Mp", "Ct", "C", "M", "K"):
+    for name in ("A", "B", "Bt", "Mp", "Ct", "C", "M", "K", "A2"):
         nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
         rp, col, val = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
         if lib.alfd_synth_matrix(owner.ptr, name.encode(), C.byref(nr), C.byref(nc), C.byref(nnz),
@@ -207,7 +222,7 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
         pb.mats[name] = Csr(nr.value, nc.value, _view(rp, nr.value + 1, C.c_int64, np.int64, owner),
                             _view(col, nnz.value, C.c_int32, np.int32, owner),
                             _view(val, nnz.value, C.c_double, np.float64, owner))
-    for name in ("f", "g", "rhs_p", "immersed_xyz"):
+    for name in ("f", "g", "rhs_p", "f2", "immersed_xyz"):
         n, data = C.c_int64(), C.POINTER(C.c_double)()
         if lib.alfd_synth_vector(owner.ptr, name.encode(), C.byref(n), C.byref(data)) != 0:
             continue
@@ -251,3 +266,14 @@ def stokes2d_circle(n_cells=32, immersed_refine=4, gamma_grad_div=10.0, coupling
                     gamma_grad_div=gamma_grad_div, center=(0.5, 0.5, 0.0), radius=0.2,
                     immersed_refine=immersed_refine, coupling_nq=coupling_nq,
                     body_force=(1.0, 0.0), embedded_value=(-1.0, 1.0))
+
+
+def elliptic_interface2d(n_bg=64, n_fg=16, beta1=1.0, beta2=10.0, coupling_nq=3) -> SyntheticProblem:
+    """cfg 3: elliptic_interface 2-D + parameters_elliptic_interface/parameters_modified.prm.
+    Background Q1 on n_bg^2 cells of [-1,1]^2 (prm:53-54), immersed Q1 on n_fg^2 cells of
+    [-0.14,0.47]^2 (prm:55-56), A = beta_1 stiffness, A2 = (beta_2 - beta_1) stiffness
+    (elliptic_interface.cc:680-681), f_1 = 1, f_2 - f = 1 (prm:19-29).  beta_2 = 10 in the
+    prm (:5); BASELINE.json quotes a jump of 1e3 -- both are valid inputs."""
+    return generate(dim=2, degree=1, ncomp=1, n_cells=n_bg, lo=-1.0, hi=1.0, beta=beta1,
+                    coupling_nq=coupling_nq, body_force=(1.0,), embedded_value=(0.0,),
+                    immersed_box=(-0.14, 0.47, n_fg), beta2=beta2 - beta1)

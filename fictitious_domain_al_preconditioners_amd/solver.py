@@ -304,6 +304,14 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config) -> Context:
     ctx.set_matrix(_abi.A, pb.mats["A"])
     ctx.set_matrix(_abi.CT, pb.mats["Ct"])
     ctx.set_matrix(_abi.C_, pb.mats["C"])
+    if "A2" in pb.mats:
+        # elliptic interface: W^-1 = 1/(M^2)_ii (utilities.h:348-374, elliptic_interface.cc:726)
+        ctx.set_matrix(_abi.A2, pb.mats["A2"])
+        ctx.set_matrix(_abi.M, pb.mats["M"])
+        ctx.set_diag(_abi.INVW, pb.inv_w_diag_of_mass_squared())
+        ctx.configure(cfg)
+        ctx.setup(pb.block_sizes)
+        return ctx
     ctx.set_diag(_abi.INVW, pb.inv_w_diag_squared())
     if "B" in pb.mats:
         ctx.set_matrix(_abi.BT, pb.mats["Bt"])
@@ -350,6 +358,18 @@ class BlockPreconditionerAugmentedLagrangianStokes(_ALPreconditionerBase):
 class BlockPreconditionerAugmentedLagrangianDiagonal(_ALPreconditionerBase):
     """augmented_lagrangian_preconditioner.h:81-110."""
     variant = _abi.AL_STOKES_DIAG
+
+
+class BlockTriangularALPreconditioner(_ALPreconditionerBase):
+    """EllipticInterfacePreconditioners::BlockTriangularALPreconditioner,
+    augmented_lagrangian_preconditioner.h:115-164."""
+    variant = _abi.AL_ELL_IDEAL
+
+
+class BlockTriangularALPreconditionerModified(_ALPreconditionerBase):
+    """EllipticInterfacePreconditioners::BlockTriangularALPreconditionerModified,
+    augmented_lagrangian_preconditioner.h:168-238."""
+    variant = _abi.AL_ELL_MODIFIED
 
 
 class SystemOperator:

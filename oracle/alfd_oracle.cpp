@@ -220,8 +220,9 @@ struct Problem {
   int64_t off[ALFD_MAX_BLOCKS + 1] = {0, 0, 0, 0};  // padded offsets
   alfd_config cfg;
   // setup products
-  std::vector<double> dinv_aug;  // 1/diag(Aug)
-  double lambda_max = 0, lambda_min = 0;
+  std::vector<double> dinv_aug, dinv_a22, dinv_aug2;  // 1/diag of the inner operators
+  double lam_max[4] = {0, 0, 0, 0};                   // per inner operator kind
+  double lambda_max = 0;
   // stats
   int64_t inner_its = 0, mp_its = 0;
   int inner_failures = 0, precond_applications = 0;
@@ -262,27 +263,79 @@ static void transpose_into(const Csr &a, Csr &t) {
   t.val = t.own_val.data();
 }
 
-// Aug x = A x + gamma Ct (w .* (C x))   (stokes...:991-993, immersed_laplace.cc:883)
-static void aug_apply(Problem &P, const double *x, double *y, std::vector<double> &t) {
-  const Csr &A = P.mat[ALFD_A], &Ct = P.mat[ALFD_CT], &C = P.mat[ALFD_C];
-  spmv(A, x, y, 0, 0.0);
-  t.resize(C.nrows);
-  spmv(C, x, t.data(), 0, 0.0);
-  pmul(C.nrows, P.diag[ALFD_INVW], t.data(), t.data());
-  spmv(Ct, t.data(), y, 1, P.cfg.gamma);
-}
+// ---- inner operators -------------------------------------------------------
+// kind 0: Aug  x = A x + gamma Ct (w .* (C x))        (stokes...:991-993, immersed_laplace.cc:883,
+//                                                       A11_aug elliptic...:807)
+// kind 1: Mp
+// kind 2: A22  x = A2 x + gamma2 M (w .* (M x))        (A22_aug, elliptic_interface.cc:810)
+// kind 3: the 2x2 block [[A11_aug, A12_aug],[A21_aug, A22_aug]] on [x0 | pad | x1]
+//         (elliptic_interface.cc:927-929), with s = C x0 - M x1, t = w .* s:
+//           y0 = A x0 + gamma Ct t ,  y1 = A2 x1 - gamma2 M t
+enum { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3 };
 
-struct AugOp {
+struct InnerOp {
   Problem &P;
+  int kind;
   std::vector<double> t;
-  void operator()(const double *x, double *y) { aug_apply(P, x, y, t); }
-  int64_t n() const { return P.n[0]; }
+  int64_t n() const { return kind == OP_AUG ? P.n[0] : kind == OP_AUG2 ? P.off[2] : P.n[1]; }
+  int blk() const { return kind == OP_AUG ? 0 : kind == OP_AUG2 ? -1 : 1; }
+  void operator()(const double *x, double *y) {
+    const double *w = P.diag[ALFD_INVW];
+    if (kind == OP_AUG) {
+      const Csr &C = P.mat[ALFD_C];
+      spmv(P.mat[ALFD_A], x, y, 0, 0.0);
+      t.resize(C.nrows);
+      spmv(C, x, t.data(), 0, 0.0);
+      pmul(C.nrows, w, t.data(), t.data());
+      spmv(P.mat[ALFD_CT], t.data(), y, 1, P.cfg.gamma);
+    } else if (kind == OP_MP) {
+      spmv(P.mat[ALFD_MP], x, y, 0, 0.0);
+    } else if (kind == OP_A22) {
+      const Csr &M = P.mat[ALFD_M];
+      spmv(P.mat[ALFD_A2], x, y, 0, 0.0);
+      t.resize(M.nrows);
+      spmv(M, x, t.data(), 0, 0.0);
+      pmul(M.nrows, w, t.data(), t.data());
+      spmv(M, t.data(), y, 1, P.cfg.gamma2);
+    } else {
+      const Csr &C = P.mat[ALFD_C], &M = P.mat[ALFD_M];
+      const double *x0 = x, *x1 = x + P.off[1];
+      double *y0 = y, *y1 = y + P.off[1];
+      t.resize(C.nrows);
+      spmv(C, x0, t.data(), 0, 0.0);
+      spmv(M, x1, t.data(), 1, -1.0);                    // s = C x0 - M x1
+      pmul(C.nrows, w, t.data(), t.data());
+      spmv(P.mat[ALFD_A], x0, y0, 0, 0.0);
+      spmv(P.mat[ALFD_CT], t.data(), y0, 1, P.cfg.gamma);
+      spmv(P.mat[ALFD_A2], x1, y1, 0, 0.0);
+      spmv(M, t.data(), y1, 1, -P.cfg.gamma2);
+      for (int64_t i = P.n[0]; i < P.off[1]; ++i) y[i] = 0.0;  // padding between the blocks
+    }
+  }
 };
-struct MatOp {
-  const Csr &m;
-  void operator()(const double *x, double *y) { spmv(m, x, y, 0, 0.0); }
-  int64_t n() const { return m.nrows; }
-};
+
+// reductions of an inner solve: one block, or blocks 0..1 of the block vector
+static double idot(const Problem &P, int blk, int64_t n, const double *x, const double *y) {
+  if (blk >= 0) return bdot(P, blk, x, y);
+  if (P.pt.nranks <= 1) return dot(n, x, y);
+  double total = 0.0;
+  for (int r = 0; r < P.pt.nranks; ++r) {
+    int64_t loc_off[3] = {0, 0, 0};
+    for (int b = 0; b < 2; ++b) {
+      const int64_t nl = P.pt.offs[b][r + 1] - P.pt.offs[b][r];
+      loc_off[b + 1] = (loc_off[b] + nl + CHUNK - 1) / CHUNK * CHUNK;
+    }
+    std::vector<double> lx(loc_off[2], 0.0), ly(loc_off[2], 0.0);
+    for (int b = 0; b < 2; ++b) {
+      const int64_t g0 = P.pt.offs[b][r], nl = P.pt.offs[b][r + 1] - g0;
+      std::memcpy(&lx[loc_off[b]], x + P.off[b] + g0, nl * sizeof(double));
+      std::memcpy(&ly[loc_off[b]], y + P.off[b] + g0, nl * sizeof(double));
+    }
+    const double d = dot(loc_off[2], lx.data(), ly.data());
+    total = r == 0 ? d : total + d;
+  }
+  return total;
+}
 
 // Preconditioners of the inner CG.
 struct IdentityPrec {
@@ -292,17 +345,17 @@ struct DiagPrec {
   const double *dinv;
   void operator()(const double *r, double *z, int64_t n) { pmul(n, dinv, r, z); }
 };
-// Chebyshev polynomial of degree k in D^-1 Aug (Saad, Alg. 12.1, zero start).
+// Chebyshev polynomial of degree k in D^-1 Op (Saad, Alg. 12.1, zero start).
 struct ChebPrec {
   Problem &P;
-  AugOp &op;
+  InnerOp &op;
+  const double *dinv;
+  double lmax, lmin;
   std::vector<double> d, res, tmp;
   void operator()(const double *r, double *z, int64_t n) {
-    const double lmax = P.lambda_max, lmin = P.lambda_min;
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
     const double sigma = theta / delta;
     double rho = 1.0 / sigma;
-    const double *dinv = P.dinv_aug.data();
     d.resize(n);
     res.resize(n);
     tmp.resize(n);
@@ -314,7 +367,7 @@ struct ChebPrec {
     }
     if (P.cfg.cheb_degree > 1) std::memcpy(res.data(), r, n * sizeof(double));
     for (int j = 1; j < P.cfg.cheb_degree; ++j) {
-      op(d.data(), tmp.data());  // tmp = Aug d
+      op(d.data(), tmp.data());
       const double rho_new = 1.0 / (2.0 * sigma - rho);
       const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
 #pragma omp parallel for schedule(static)
@@ -329,20 +382,22 @@ struct ChebPrec {
 };
 
 // deal.II SolverCG through inverse_operator: zero initial guess [EXT].
-template <class Op, class Prec>
-static State pcg(const Problem &P, int blk, Op &op, Prec &prec, const alfd_control &ctrl, const double *b,
-                 double *x, int64_t n, int &its, double &last_res, int log_level, const char *tag) {
+template <class Prec>
+static State pcg(const Problem &P, InnerOp &op, Prec &prec, const alfd_control &ctrl, const double *b,
+                 double *x, int &its, double &last_res, int log_level, const char *tag) {
+  const int64_t n = op.n();
+  const int blk = op.blk();
   std::vector<double> r(b, b + n), z(n), p(n), Ap(n);
   std::fill(x, x + n, 0.0);
   Control sc{ctrl};
-  double res = std::sqrt(bdot(P, blk, r.data(), r.data()));
+  double res = std::sqrt(idot(P, blk, n, r.data(), r.data()));
   State st = sc.check(0, res);
   its = 0;
   double rz_old = 0.0;
   while (st == ITERATE) {
     ++its;
     prec(r.data(), z.data(), n);
-    const double rz = bdot(P, blk, r.data(), z.data());
+    const double rz = idot(P, blk, n, r.data(), z.data());
     if (its > 1) {
       const double beta = rz / rz_old;
       xpby(n, z.data(), beta, p.data());
@@ -350,11 +405,11 @@ static State pcg(const Problem &P, int blk, Op &op, Prec &prec, const alfd_contr
       std::memcpy(p.data(), z.data(), n * sizeof(double));
     }
     op(p.data(), Ap.data());
-    const double pAp = bdot(P, blk, p.data(), Ap.data());
+    const double pAp = idot(P, blk, n, p.data(), Ap.data());
     const double alpha = rz / pAp;
     axpy(n, alpha, p.data(), x);
     axpy(n, -alpha, Ap.data(), r.data());
-    res = std::sqrt(bdot(P, blk, r.data(), r.data()));
+    res = std::sqrt(idot(P, blk, n, r.data(), r.data()));
     st = sc.check(its, res);
     rz_old = rz;
     if (log_level >= 3) std::printf("DEAL:%s:cg::Check %d\t%.17g\n", tag, its, res);
@@ -363,24 +418,34 @@ static State pcg(const Problem &P, int blk, Op &op, Prec &prec, const alfd_contr
   return st;
 }
 
-static int inner_solve_aug(Problem &P, const double *b, double *x) {
-  AugOp op{P, {}};
+// dinv / lambda of the inner operator `kind`
+static const double *op_dinv(const Problem &P, int kind) {
+  return kind == OP_AUG ? P.dinv_aug.data() : kind == OP_A22 ? P.dinv_a22.data() : P.dinv_aug2.data();
+}
+
+static int inner_solve(Problem &P, int kind, const double *b, double *x) {
+  InnerOp op{P, kind, {}};
   int its = 0;
   double res = 0;
   State st;
-  const int64_t n = P.n[0];
-  if (P.cfg.inner_prec == ALFD_PREC_IDENTITY) {
-    IdentityPrec pr;
-    st = pcg(P, 0, op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
-  } else if (P.cfg.inner_prec == ALFD_PREC_JACOBI) {
-    DiagPrec pr{P.dinv_aug.data()};
-    st = pcg(P, 0, op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
+  if (kind == OP_MP) {
+    DiagPrec pr{P.diag[ALFD_MP_LUMPED_INV]};
+    st = pcg(P, op, pr, P.cfg.mp_inner, b, x, its, res, P.cfg.log_level, "mp");
+    P.mp_its += its;
   } else {
-    AugOp op2{P, {}};
-    ChebPrec pr{P, op2, {}, {}, {}};
-    st = pcg(P, 0, op, pr, P.cfg.inner, b, x, n, its, res, P.cfg.log_level, "aug");
+    if (P.cfg.inner_prec == ALFD_PREC_IDENTITY) {
+      IdentityPrec pr;
+      st = pcg(P, op, pr, P.cfg.inner, b, x, its, res, P.cfg.log_level, "aug");
+    } else if (P.cfg.inner_prec == ALFD_PREC_JACOBI) {
+      DiagPrec pr{op_dinv(P, kind)};
+      st = pcg(P, op, pr, P.cfg.inner, b, x, its, res, P.cfg.log_level, "aug");
+    } else {
+      InnerOp op2{P, kind, {}};
+      ChebPrec pr{P, op2, op_dinv(P, kind), P.lam_max[kind], P.lam_max[kind] / P.cfg.cheb_eig_ratio, {}, {}, {}};
+      st = pcg(P, op, pr, P.cfg.inner, b, x, its, res, P.cfg.log_level, "aug");
+    }
+    P.inner_its += its;
   }
-  P.inner_its += its;
   if (st == FAILURE) {
     if (std::isnan(res)) return ALFD_E_BREAKDOWN;
     if (P.cfg.on_inner_failure == ALFD_INNER_THROW) return ALFD_E_NO_CONVERGENCE_INNER;
@@ -389,56 +454,74 @@ static int inner_solve_aug(Problem &P, const double *b, double *x) {
   return ALFD_OK;
 }
 
-static int inner_solve_mp(Problem &P, const double *b, double *x) {
-  MatOp op{P.mat[ALFD_MP]};
-  DiagPrec pr{P.diag[ALFD_MP_LUMPED_INV]};
-  int its = 0;
-  double res = 0;
-  State st = pcg(P, 1, op, pr, P.cfg.mp_inner, b, x, P.n[1], its, res, P.cfg.log_level, "mp");
-  P.mp_its += its;
-  if (st == FAILURE) {
-    if (std::isnan(res)) return ALFD_E_BREAKDOWN;
-    if (P.cfg.on_inner_failure == ALFD_INNER_THROW) return ALFD_E_NO_CONVERGENCE_INNER;
-    P.inner_failures++;
-  }
-  return ALFD_OK;
-}
+static bool is_elliptic(int v) { return v == ALFD_AL_ELL_IDEAL || v == ALFD_AL_ELL_MODIFIED; }
 
-// diag(Aug)_i = A_ii + gamma sum_k w_k Ct_ik^2 (sequential fma over the row of
-// Ct); lambda_max(D^-1 Aug) by power iteration from a
-// deterministic integer-hash start vector.
-static void setup(Problem &P) {
-  const Csr &A = P.mat[ALFD_A], &Ct = P.mat[ALFD_CT];
-  const int64_t n = P.n[0];
-  P.dinv_aug.assign(n, 0.0);
-  const double *w = P.diag[ALFD_INVW];
+// diagonals of the inner operators and lambda_max(D^-1 Op) by power iteration
+// from a deterministic integer-hash start vector.
+//   diag(Aug)_i = A_ii  + gamma  sum_k w_k Ct_ik^2   (sequential fma over row i of Ct)
+//   diag(A22)_i = A2_ii + gamma2 sum_k w_k M_ik^2    (row i of M)
+static void diag_plus(const Csr &A, const Csr &R, const double *w, double g, int64_t n, double *dinv) {
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     double d = 0.0;
     for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k)
       if (A.col[k] == i) d = A.val[k];
     double s = 0.0;
-    for (int64_t k = Ct.rp[i]; k < Ct.rp[i + 1]; ++k) s = std::fma(w[Ct.col[k]] * Ct.val[k], Ct.val[k], s);
-    P.dinv_aug[i] = 1.0 / std::fma(P.cfg.gamma, s, d);
+    for (int64_t k = R.rp[i]; k < R.rp[i + 1]; ++k) s = std::fma(w[R.col[k]] * R.val[k], R.val[k], s);
+    dinv[i] = 1.0 / std::fma(g, s, d);
   }
-  P.lambda_max = P.lambda_min = 0.0;
-  if (P.cfg.inner_prec == ALFD_PREC_CHEBYSHEV) {
-    std::vector<double> v(n), wv(n);
-    for (int64_t i = 0; i < n; ++i)
-      v[i] = 1.0 + (double)(((uint64_t)i * 2654435761ull) & 1023ull) * (1.0 / 1024.0);
-    AugOp op{P, {}};
-    double lam = 0.0;
-    for (int it = 0; it < P.cfg.cheb_power_its; ++it) {
-      const double nv = std::sqrt(bdot(P, 0, v.data(), v.data()));
-      scale(n, 1.0 / nv, v.data());
-      op(v.data(), wv.data());
-      pmul(n, P.dinv_aug.data(), wv.data(), wv.data());
-      lam = std::sqrt(bdot(P, 0, wv.data(), wv.data()));
-      v.swap(wv);
+}
+
+static void power_iteration(Problem &P, int kind) {
+  InnerOp op{P, kind, {}};
+  const int64_t n = op.n();
+  const int blk = op.blk();
+  const double *dinv = op_dinv(P, kind);
+  std::vector<double> v(n, 0.0), wv(n, 0.0);
+  auto fill = [&](int64_t off, int64_t len) {
+    for (int64_t i = 0; i < len; ++i)
+      v[off + i] = 1.0 + (double)(((uint64_t)i * 2654435761ull) & 1023ull) * (1.0 / 1024.0);
+  };
+  if (kind == OP_AUG2) {
+    fill(0, P.n[0]);
+    fill(P.off[1], P.n[1]);
+  } else {
+    fill(0, n);
+  }
+  double lam = 0.0;
+  for (int it = 0; it < P.cfg.cheb_power_its; ++it) {
+    const double nv = std::sqrt(idot(P, blk, n, v.data(), v.data()));
+    scale(n, 1.0 / nv, v.data());
+    op(v.data(), wv.data());
+    pmul(n, dinv, wv.data(), wv.data());
+    lam = std::sqrt(idot(P, blk, n, wv.data(), wv.data()));
+    v.swap(wv);
+  }
+  P.lam_max[kind] = lam * P.cfg.cheb_safety;
+}
+
+static void setup(Problem &P) {
+  const double *w = P.diag[ALFD_INVW];
+  P.dinv_aug.assign(P.n[0], 0.0);
+  diag_plus(P.mat[ALFD_A], P.mat[ALFD_CT], w, P.cfg.gamma, P.n[0], P.dinv_aug.data());
+  for (int k = 0; k < 4; ++k) P.lam_max[k] = 0.0;
+  const bool cheb = P.cfg.inner_prec == ALFD_PREC_CHEBYSHEV;
+  if (is_elliptic(P.cfg.variant)) {
+    P.dinv_a22.assign(P.n[1], 0.0);
+    diag_plus(P.mat[ALFD_A2], P.mat[ALFD_M], w, P.cfg.gamma2, P.n[1], P.dinv_a22.data());
+    if (P.cfg.variant == ALFD_AL_ELL_IDEAL) {
+      P.dinv_aug2.assign(P.off[2], 0.0);
+      std::copy(P.dinv_aug.begin(), P.dinv_aug.end(), P.dinv_aug2.begin());
+      std::copy(P.dinv_a22.begin(), P.dinv_a22.end(), P.dinv_aug2.begin() + P.off[1]);
+      if (cheb) power_iteration(P, OP_AUG2);
+    } else if (cheb) {
+      power_iteration(P, OP_AUG);
+      power_iteration(P, OP_A22);
     }
-    P.lambda_max = lam * P.cfg.cheb_safety;
-    P.lambda_min = P.lambda_max / P.cfg.cheb_eig_ratio;
+  } else if (cheb) {
+    power_iteration(P, OP_AUG);
   }
+  P.lambda_max = P.lam_max[is_elliptic(P.cfg.variant) && P.cfg.variant == ALFD_AL_ELL_IDEAL ? OP_AUG2 : OP_AUG];
 }
 
 // ------------------------------------------------- preconditioner vmult
@@ -455,7 +538,7 @@ static int precond_apply(Problem &P, const double *u, double *v) {
     pmul_scale(P.n[1], -c.gamma, w, u1, v1);            // v1 = -gamma invW u1
     std::vector<double> tmp(u0, u0 + P.n[0]);
     spmv(P.mat[ALFD_CT], v1, tmp.data(), 1, -1.0);      // tmp = u0 - Ct v1
-    return inner_solve_aug(P, tmp.data(), v0);          // v0 = Aug_inv tmp
+    return inner_solve(P, OP_AUG, tmp.data(), v0);      // v0 = Aug_inv tmp
   }
   if (c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG) {
     // :62-70 (triangular) and :95-103 (diagonal SPD)
@@ -465,7 +548,7 @@ static int precond_apply(Problem &P, const double *u, double *v) {
     double *v0 = v + P.off[0], *v1 = v + P.off[1], *v2 = v + P.off[2];
     pmul_scale(P.n[2], sgn * c.gamma, w, u2, v2);       // v2 = -+gamma invW u2
     std::vector<double> q(P.n[1]);
-    int rc = inner_solve_mp(P, u1, q.data());           // Mp_inv u1
+    int rc = inner_solve(P, OP_MP, u1, q.data());       // Mp_inv u1
     if (rc != ALFD_OK) return rc;
     const double s1 = sgn * c.gamma_grad_div;
     for (int64_t i = 0; i < P.n[1]; ++i) v1[i] = s1 * q[i];
@@ -474,12 +557,42 @@ static int precond_apply(Problem &P, const double *u, double *v) {
       spmv(P.mat[ALFD_BT], v1, tmp.data(), 1, -1.0);    // - Bt v1
       spmv(P.mat[ALFD_CT], v2, tmp.data(), 1, -1.0);    // - Ct v2
     }
-    return inner_solve_aug(P, tmp.data(), v0);
+    return inner_solve(P, OP_AUG, tmp.data(), v0);
+  }
+  if (c.variant == ALFD_AL_ELL_MODIFIED) {
+    // BlockTriangularALPreconditionerModified::vmult, ...preconditioner.h:225-228:
+    //   d2 = -gamma invW lambda
+    //   d1 = A22_inv (u2 + M d2)
+    //   d0 = A11_inv (u + gamma Ct invW M d1 - Ct d2)
+    const double *u0 = u + P.off[0], *u1 = u + P.off[1], *u2 = u + P.off[2];
+    double *d0 = v + P.off[0], *d1 = v + P.off[1], *d2 = v + P.off[2];
+    pmul_scale(P.n[2], -c.gamma, w, u2, d2);
+    std::vector<double> r1(u1, u1 + P.n[1]);
+    spmv(P.mat[ALFD_M], d2, r1.data(), 1, 1.0);
+    int rc = inner_solve(P, OP_A22, r1.data(), d1);
+    if (rc != ALFD_OK) return rc;
+    std::vector<double> t(P.n[2]), r0(u0, u0 + P.n[0]);
+    spmv(P.mat[ALFD_M], d1, t.data(), 0, 0.0);
+    pmul(P.n[2], w, t.data(), t.data());
+    spmv(P.mat[ALFD_CT], t.data(), r0.data(), 1, c.gamma);
+    spmv(P.mat[ALFD_CT], d2, r0.data(), 1, -1.0);
+    return inner_solve(P, OP_AUG, r0.data(), d0);
+  }
+  if (c.variant == ALFD_AL_ELL_IDEAL) {
+    // BlockTriangularALPreconditioner::vmult, ...preconditioner.h:130-156:
+    //   v2 = -gamma invW u2 ; [v0;v1] = Aug2x2_inv [u0 - Ct v2 ; u1 + M v2]
+    const double *u2 = u + P.off[2];
+    double *v2 = v + P.off[2];
+    pmul_scale(P.n[2], -c.gamma, w, u2, v2);
+    std::vector<double> uu(u, u + P.off[2]);
+    spmv(P.mat[ALFD_CT], v2, uu.data(), 1, -1.0);
+    spmv(P.mat[ALFD_M], v2, uu.data() + P.off[1], 1, 1.0);
+    return inner_solve(P, OP_AUG2, uu.data(), v);
   }
   return ALFD_E_UNSUPPORTED;
 }
 
-// AA y = ... (immersed_laplace.cc:891-892, stokes...:1000-1003)
+// AA y = ... (immersed_laplace.cc:891-892, stokes...:1000-1003, elliptic...:816-819)
 static int system_apply(Problem &P, const double *x, double *y) {
   const alfd_config &c = P.cfg;
   std::fill(y, y + P.ntot(), 0.0);
@@ -499,6 +612,26 @@ static int system_apply(Problem &P, const double *x, double *y) {
       spmv(P.mat[ALFD_B], x0, y + P.off[1], 0, 0.0);    // y1 = B x0
     }
     spmv(P.mat[ALFD_CT], xl, y0, 1, 1.0);               // + Ct x_lambda
+    return ALFD_OK;
+  }
+  if (is_elliptic(c.variant)) {
+    // [[A11_aug, A12_aug, Ct],[A21_aug, A22_aug, -M],[C, -M, 0]] with
+    // A12_aug = -gamma Ct invW M, A21_aug = -gamma2 M invW C (elliptic...:810-819):
+    //   y2 = C x0 - M x1 ; t = w .* y2
+    //   y0 = A x0 + gamma Ct t + Ct x2 ; y1 = A2 x1 - gamma2 M t - M x2
+    const double *x0 = x + P.off[0], *x1 = x + P.off[1], *x2 = x + P.off[2];
+    double *y0 = y + P.off[0], *y1 = y + P.off[1], *y2 = y + P.off[2];
+    const Csr &M = P.mat[ALFD_M];
+    spmv(P.mat[ALFD_C], x0, y2, 0, 0.0);
+    spmv(M, x1, y2, 1, -1.0);
+    std::vector<double> t(P.n[2]);
+    pmul(P.n[2], w, y2, t.data());
+    spmv(P.mat[ALFD_A], x0, y0, 0, 0.0);
+    spmv(P.mat[ALFD_CT], t.data(), y0, 1, c.gamma);
+    spmv(P.mat[ALFD_CT], x2, y0, 1, 1.0);
+    spmv(P.mat[ALFD_A2], x1, y1, 0, 0.0);
+    spmv(M, t.data(), y1, 1, -c.gamma2);
+    spmv(M, x2, y1, 1, -1.0);
     return ALFD_OK;
   }
   return ALFD_E_UNSUPPORTED;
@@ -654,7 +787,11 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
   for (int d = 0; d < ALFD_NDIAGS; ++d) P.diag[d] = op->diag[d];
   if (!P.mat[ALFD_A].present() || !P.mat[ALFD_CT].present() || !P.diag[ALFD_INVW]) return ALFD_E_INVALID;
   if (!P.mat[ALFD_C].present()) orc::transpose_into(P.mat[ALFD_CT], P.mat[ALFD_C]);
-  if (P.nblocks == 3) {
+  const bool ell = cfg->variant == ALFD_AL_ELL_IDEAL || cfg->variant == ALFD_AL_ELL_MODIFIED;
+  if (ell) {
+    if (P.nblocks != 3 || !P.mat[ALFD_A2].present() || !P.mat[ALFD_M].present() || P.n[1] != P.n[2])
+      return ALFD_E_INVALID;
+  } else if (P.nblocks == 3) {
     if (!P.mat[ALFD_BT].present() || !P.mat[ALFD_MP].present() || !P.diag[ALFD_MP_LUMPED_INV])
       return ALFD_E_INVALID;
     if (!P.mat[ALFD_B].present()) orc::transpose_into(P.mat[ALFD_BT], P.mat[ALFD_B]);

@@ -163,6 +163,10 @@ class OracleSystem:
 def system_from_problem(pb, nranks_emulated=1, part_offsets=None) -> OracleSystem:
     """Wrap a problems.SyntheticProblem: W^-1 = 1/M_ii^2, Mp lumped inverse."""
     mats = {k: pb.mats[k] for k in ("A", "Ct", "C") if k in pb.mats}
+    if "A2" in pb.mats:     # elliptic interface: W^-1 = 1/(M^2)_ii (elliptic_interface.cc:726)
+        mats.update({"A2": pb.mats["A2"], "M": pb.mats["M"]})
+        return OracleSystem(mats, {_abi.INVW: pb.inv_w_diag_of_mass_squared()}, pb.block_sizes,
+                            nranks_emulated, part_offsets)
     diags = {_abi.INVW: pb.inv_w_diag_squared()}
     if "B" in pb.mats:
         mats.update({k: pb.mats[k] for k in ("B", "Bt", "Mp")})

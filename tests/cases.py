@@ -5,6 +5,8 @@ from fictitious_domain_al_preconditioners_amd import _abi, problems
 
 
 def rhs_of(pb):
+    if "A2" in pb.mats:   # elliptic_interface: last row of the rhs is 0 (elliptic_interface.cc:903)
+        return [pb.vecs["f"].copy(), pb.vecs["f2"].copy(), np.zeros(pb.block_sizes[2])]
     if "B" in pb.mats:
         return [pb.vecs["f"].copy(), pb.vecs["rhs_p"].copy(), pb.vecs["g"].copy()]
     return [pb.vecs["f"].copy(), pb.vecs["g"].copy()]
@@ -46,6 +48,15 @@ def case(name):
         cfg.restart = 3
         cfg.inner_prec = _abi.PREC_IDENTITY
         cfg.inner.max_steps = 5000
+    elif name in ("elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3"):
+        # BASELINE cfg 3: elliptic_interface 2-D, parameters_modified.prm / parameters_ideal.prm
+        beta2 = 1e3 if name.endswith("1e3") else 10.0      # prm:5 says 10, BASELINE.json says 1e3
+        pb = problems.elliptic_interface2d(64, 16, beta2=beta2)
+        ideal = name == "elliptic_ideal"
+        cfg = _abi.default_config(_abi.AL_ELL_IDEAL if ideal else _abi.AL_ELL_MODIFIED)
+        cfg.gamma, cfg.gamma2 = 10.0, (10.0 if ideal else 1e-2)            # prm:48-49
+        cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 100000, 1e-2, 1e-20)  # prm:59-66
+        cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-10)   # prm:76-83
     else:
         raise KeyError(name)
     cfg.inner.max_steps = max(cfg.inner.max_steps, 1000)
@@ -53,4 +64,4 @@ def case(name):
 
 
 ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes2d_circle", "stokes3d_sphere",
-             "stokes3d_restart"]
+             "stokes3d_restart", "elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3"]

@@ -184,6 +184,23 @@ def test_reference_shaped_interface(ctxs):
         solver.BlockPreconditionerAugmentedLagrangian(ctx)       # wrong variant for this context
 
 
+def test_elliptic_reference_shaped_classes(ctxs):
+    pb, cfg, ctx, osys = ctxs("elliptic_modified")
+    P = solver.BlockTriangularALPreconditionerModified(ctx)
+    v = [np.zeros(n) for n in pb.block_sizes]
+    P.vmult(v, cases.rng_blocks(pb, 2))
+    assert P.last_result.inner_iterations > 0
+    with pytest.raises(ValueError):
+        solver.BlockTriangularALPreconditioner(ctx)
+    # the reference's parameter assertions (elliptic_interface.cc:874-884) surface as errors
+    bad = cases.case("elliptic_modified")[1]
+    bad.gamma2 = 10.0
+    c2 = solver.Context(0)
+    with pytest.raises(solver.AlfdError):
+        solver.upload_problem(c2, pb, bad)
+    c2.close()
+
+
 def test_error_behaviour(ctxs):
     """NoConvergence from the inner CG (reference: throws, stokes...:1020-1024) and
     from FGMRES; ACCEPT policy; unknown slot; unconfigured context."""

@@ -237,3 +237,64 @@ def test_rational_constants_known_answer():
     xs = np.geomspace(1e-6, 1.0, 200)
     vals = [lib.orc_rational_eval(20, res.ctypes.data, poles.ctypes.data, float(x)) for x in xs]
     assert np.all(np.diff(vals) > 0)
+
+
+def _assemble_elliptic(pb, cfg):
+    """elliptic_interface.cc:805-819, assembled independently with SciPy."""
+    A, Ct, C, A2, M = (pb.mats[k].to_scipy() for k in ("A", "Ct", "C", "A2", "M"))
+    W = sp.diags(pb.inv_w_diag_of_mass_squared())
+    a11 = A + cfg.gamma * (Ct @ W @ C)
+    a22 = A2 + cfg.gamma2 * (M @ W @ M)
+    a12 = -cfg.gamma * (Ct @ W @ M)
+    a21 = -cfg.gamma2 * (M @ W @ C)
+    return sp.bmat([[a11, a12, Ct], [a21, a22, -M], [C, -M, None]]).tocsc(), a11.tocsc(), a22.tocsc()
+
+
+@pytest.mark.parametrize("name", ["elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3"])
+def test_elliptic_interface_system_and_solve(name):
+    pb, cfg = cases.case(name)
+    osys = oracle.system_from_problem(pb)
+    K, _, _ = _assemble_elliptic(pb, cfg)
+    src = cases.rng_blocks(pb, 4)
+    rc, dst = osys.system_apply(cfg, src)
+    assert rc == 0
+    ref = K @ np.concatenate(src)
+    assert np.allclose(np.concatenate(dst), ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
+    rhs = cases.rhs_of(pb)
+    rc, x, res, hist = osys.solve(cfg, rhs)
+    assert rc == 0
+    r = K @ np.concatenate(x) - np.concatenate(rhs)
+    assert np.linalg.norm(r) <= 2 * max(cfg.outer.tol, cfg.outer.reduce * res.initial_residual)
+    xs = spla.spsolve(K, np.concatenate(rhs))                    # the system is non-singular
+    n0, n1 = pb.block_sizes[0], pb.block_sizes[1]
+    assert np.linalg.norm(np.concatenate(x)[:n0 + n1] - xs[:n0 + n1]) <= 1e-7 * np.linalg.norm(xs[:n0 + n1])
+    # constraint row: C u - M u2 = 0 (elliptic_interface.cc:973-984 prints this residual)
+    cu = pb.mats["C"].to_scipy() @ x[0] - pb.mats["M"].to_scipy() @ x[1]
+    assert np.abs(cu).max() <= 1e-9
+
+
+def test_elliptic_modified_vmult_algebra():
+    """...preconditioner.h:225-228 with (nearly) exact inner solves."""
+    pb, cfg = cases.case("elliptic_modified")
+    cfg.inner = _abi.Control(_abi.CTRL_ABS, 20000, 1e-12, 0.0)
+    osys = oracle.system_from_problem(pb)
+    u = cases.rng_blocks(pb, 8)
+    rc, v, res = osys.precond_apply(cfg, u)
+    assert rc == 0
+    _, a11, a22 = _assemble_elliptic(pb, cfg)
+    w = pb.inv_w_diag_of_mass_squared()
+    Ct, M = pb.mats["Ct"].to_scipy(), pb.mats["M"].to_scipy()
+    d2 = -cfg.gamma * w * u[2]
+    d1 = spla.spsolve(a22, u[1] + M @ d2)
+    d0 = spla.spsolve(a11, u[0] + cfg.gamma * (Ct @ (w * (M @ d1))) - Ct @ d2)
+    assert np.allclose(v[2], d2, rtol=1e-14, atol=0)
+    assert np.linalg.norm(v[1] - d1) <= 1e-8 * np.linalg.norm(d1)
+    assert np.linalg.norm(v[0] - d0) <= 1e-8 * np.linalg.norm(d0)
+
+
+def test_elliptic_parameter_sanity_is_enforced_by_the_prm_reader():
+    from fictitious_domain_al_preconditioners_amd import prm
+    t = prm.parse("subsection Elliptic Interface Problem\n subsection AL preconditioner\n"
+                  " set Use modified AL preconditioner = false\n set gamma fluid = 10\n set gamma solid = 1\n end\nend\n")
+    with pytest.raises(ValueError):      # ideal variant needs gamma_1 == gamma_2 (elliptic...:916-920)
+        prm.config_from_prm(t)
