@@ -21,6 +21,8 @@ CTRL_ABS, CTRL_REDUCTION, CTRL_FIXED_ITERS = range(3)
 PREC_IDENTITY, PREC_JACOBI, PREC_CHEBYSHEV = range(3)
 # enum alfd_orthogonalization
 ORTH_MGS, ORTH_CGS, ORTH_CGS2 = range(3)
+# enum alfd_outer_solver
+OUTER_FGMRES, OUTER_MINRES = range(2)
 # enum alfd_inner_failure_policy
 INNER_THROW, INNER_ACCEPT = range(2)
 # enum alfd_timing_class
@@ -45,7 +47,8 @@ class Config(C.Structure):
         ("inner_prec", C.c_int32), ("cheb_degree", C.c_int32), ("cheb_power_its", C.c_int32),
         ("on_inner_failure", C.c_int32),
         ("cheb_eig_ratio", C.c_double), ("cheb_safety", C.c_double),
-        ("log_level", C.c_int32), ("reserved", C.c_int32),
+        ("log_level", C.c_int32), ("outer_solver", C.c_int32),
+        ("rho_bound", C.c_double), ("rational", Control),
     ]
 
 
@@ -56,6 +59,7 @@ class Result(C.Structure):
         ("inner_iterations", C.c_int64), ("mp_iterations", C.c_int64),
         ("inner_failures", C.c_int32), ("precond_applications", C.c_int32),
         ("solve_seconds", C.c_double), ("lambda_max", C.c_double),
+        ("rational_iterations", C.c_int64),
     ]
 
     def as_dict(self):
@@ -81,4 +85,7 @@ def default_config(variant=AL_STOKES) -> Config:
     c.cheb_eig_ratio = 30.0
     c.cheb_safety = 1.2
     c.log_level = 0
+    c.outer_solver = OUTER_MINRES if variant == RATIONAL else OUTER_FGMRES
+    c.rho_bound = 0.0
+    c.rational = Control(CTRL_ABS, 2000, 1e-14, 0.0)      # rational_preconditioner.h:34
     return c

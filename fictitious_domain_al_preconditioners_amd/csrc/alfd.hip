@@ -140,7 +140,20 @@ struct alfd_ctx {
   double *gather = nullptr;    // multi-rank scalar all-gather buffer
   double *dinv_aug = nullptr, *dA = nullptr, *s_aug = nullptr;
   double *dinv_a22 = nullptr, *dinv_aug2 = nullptr;   // elliptic: 1/diag(A22_aug), [dinv_aug | dinv_a22]
-  double lam_max[4] = {0, 0, 0, 0};                    // per inner operator kind
+  double lam_max[6] = {0, 0, 0, 0, 0, 0};              // per inner operator kind
+  double *dinv_k = nullptr;                            // rational: 1/diag(K)
+  // RationalPreconditioner state (batched CG over the 21 immersed systems)
+  struct HostCsr {
+    int64_t nrows = 0, ncols = 0;
+    std::vector<int64_t> rp;
+    std::vector<int32_t> col;
+    std::vector<double> val;
+  } h_M, h_K;                                          // host copies of the (tiny) immersed matrices
+  DevCsr rat_mat;                                      // block-diagonal [S_1 .. S_20, M]
+  double *rt_r = nullptr, *rt_z = nullptr, *rt_p = nullptr, *rt_Ap = nullptr, *rt_x = nullptr;
+  double *rt_dinv = nullptr, *rt_partial = nullptr, *rt_scb = nullptr, *rt_coef = nullptr;
+  double *rt_scb_host = nullptr;
+  int64_t rational_its = 0;
   int64_t wmax = 0;                                    // length of the inner-solve work vectors
   std::vector<void *> ws_allocs;                       // workspace of the current setup()
   double *w_r = nullptr, *w_z = nullptr, *w_p = nullptr, *w_Ap = nullptr;  // PCG
@@ -482,10 +495,12 @@ static int read_scalars(alfd_ctx *ctx, int first, int count) {
 //   OP_A22   y = A2 x + gamma2 M (invW .* (M x))        A22_aug, elliptic_interface.cc:810
 //   OP_AUG2  2x2 [[A11_aug, A12_aug],[A21_aug, A22_aug]] on [x0 | pad | x1] (elliptic...:927-929):
 //            s = C x0 - M x1, t = invW .* s, y0 = A x0 + gamma Ct t, y1 = A2 x1 - gamma2 M t
-enum OpKind { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3 };
+//   OP_K     y = A x  (K_inv of the rational branch: UMFPACK in the reference,
+//            immersed_laplace.cc:617-620; here CG to alfd_config::inner)
+enum OpKind { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3, OP_K = 4 };
 
 static inline int64_t op_npad(const alfd_ctx *ctx, int op) {
-  return op == OP_AUG ? pad_chunk(ctx->n[0]) : op == OP_AUG2 ? ctx->off[2] : pad_chunk(ctx->n[1]);
+  return (op == OP_AUG || op == OP_K) ? pad_chunk(ctx->n[0]) : op == OP_AUG2 ? ctx->off[2] : pad_chunk(ctx->n[1]);
 }
 
 static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y) {
@@ -497,6 +512,8 @@ static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y) {
       return spmv(ctx, ALFD_CT, ctx->t_lam, y, 1, ctx->cfg.gamma);
     case OP_MP:
       return spmv(ctx, ALFD_MP, x, y, 0);
+    case OP_K:
+      return spmv(ctx, ALFD_A, x, y, 0);
     case OP_A22:
       RC(spmv(ctx, ALFD_A2, x, y, 0));
       RC(spmv(ctx, ALFD_M, x, ctx->t_lam, 2, 0.0, w));
@@ -518,7 +535,7 @@ static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y) {
 
 static const double *op_dinv(const alfd_ctx *ctx, int op) {
   return op == OP_AUG ? ctx->dinv_aug : op == OP_A22 ? ctx->dinv_a22 : op == OP_AUG2 ? ctx->dinv_aug2
-                                                                                      : ctx->diag[ALFD_MP_LUMPED_INV];
+         : op == OP_K ? ctx->dinv_k : ctx->diag[ALFD_MP_LUMPED_INV];
 }
 
 // Chebyshev sweep z = p_k(D^-1 Op) D^-1 r
@@ -614,6 +631,115 @@ static int inner_solve(alfd_ctx *ctx, int op, const double *b, double *x) {
 
 static inline bool is_elliptic(int v) { return v == ALFD_AL_ELL_IDEAL || v == ALFD_AL_ELL_MODIFIED; }
 
+// ---- RationalPreconditioner (rational_preconditioner.h:29-63) ----------------
+static const double kRatRes[21] = {
+    1.1133752551375149e+01,  -4.5192561264009555e+02, -5.4280235488093114e+00, -6.6119823627983498e-01,
+    -1.5483255874020074e-01, -4.8435293477731435e-02, -1.7569986796633446e-02, -6.9011933591631392e-03,
+    -2.8275585395562131e-03, -1.1823861060446343e-03, -4.9806992558149195e-04, -2.0975776516702764e-04,
+    -8.7959042415258930e-05, -3.6650480089224726e-05, -1.5149104182285630e-05, -6.1866179967421625e-06,
+    -2.4691626461139533e-06, -9.3898594542244485e-07, -3.2099152020952601e-07, -8.4169497470931466e-08,
+    -7.7616172944516437e-09};
+static const double kRatPoles[20] = {
+    -4.9917060842594275e+01, -5.2698715191349796e+00, -1.7156755741861143e+00, -7.5569620064292298e-01,
+    -3.7811376547012854e-01, -2.0130525955937850e-01, -1.1058502730933521e-01, -6.1664070123493613e-02,
+    -3.4578652087400880e-02, -1.9394206381182760e-02, -1.0845568864180035e-02, -6.0343457447149737e-03,
+    -3.3328397814762593e-03, -1.8198589302273998e-03, -9.7434812604726647e-04, -5.0332017175529794e-04,
+    -2.4317839761161207e-04, -1.0297057301403903e-04, -3.2227929557637293e-05, -3.3293811779427837e-06};
+constexpr int kRatSystems = 21;  // 20 shifted systems + the mass system
+
+// v1 = sum_i rho res_i (A_Gamma - rho p_i M)^-1 u1 + res_0 M^-1 u1 : the 21 CG solves
+// (Jacobi-preconditioned; the mass solve unpreconditioned, :54-56) run in lock step.
+static int rational_apply(alfd_ctx *ctx, const double *u1, double *v1) {
+  const int64_t npl = pad_chunk(ctx->n[1]);
+  const int cps = (int)(npl / kChunk);
+  const int64_t ntot = npl * kRatSystems;
+  const unsigned grid = (unsigned)(ntot / kChunk);
+  const alfd_control &ctl = ctx->cfg.rational;
+  double *sh = ctx->rt_scb_host;
+  hipLaunchKernelGGL(b_replicate_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, cps, u1, ctx->rt_r);
+  HIPC(hipMemsetAsync(ctx->rt_x, 0, ntot * sizeof(double), ctx->stream));
+  HIPC(hipMemsetAsync(ctx->rt_Ap, 0, ntot * sizeof(double), ctx->stream));
+  for (int s = 0; s < kRatSystems; ++s) {
+    for (int k = 0; k < kBS; ++k) sh[s * kBS + k] = 0.0;
+    sh[s * kBS + B_ACTIVE] = 1.0;
+  }
+  HIPC(hipMemcpyAsync(ctx->rt_scb, sh, kRatSystems * kBS * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  // initial residuals
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->rt_r, ctx->rt_r,
+                     ctx->rt_partial);
+  hipLaunchKernelGGL(b_final_kernel, dim3(kRatSystems), dim3(kBlock), 0, ctx->stream, ctx->rt_partial, cps,
+                     ctx->rt_scb, (int)FIN_STORE);
+  HIPC(hipMemcpyAsync(sh, ctx->rt_scb, kRatSystems * kBS * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  Control sc[kRatSystems];
+  State st[kRatSystems];
+  int its[kRatSystems];
+  int nactive = 0;
+  for (int s = 0; s < kRatSystems; ++s) {
+    sc[s] = Control{ctl};
+    its[s] = 0;
+    st[s] = sc[s].check(0, std::sqrt(sh[s * kBS + B_RR]));
+    nactive += st[s] == ITERATE;
+  }
+  int it = 0;
+  while (nactive > 0) {
+    ++it;
+    // freeze the systems that have stopped
+    for (int s = 0; s < kRatSystems; ++s) sh[s * kBS + B_ACTIVE] = st[s] == ITERATE ? 1.0 : 0.0;
+    for (int s = 0; s < kRatSystems; ++s)
+      HIPC(hipMemcpyAsync(ctx->rt_scb + s * kBS + B_ACTIVE, sh + s * kBS + B_ACTIVE, sizeof(double),
+                          hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(b_jacobi_dot_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->rt_scb, cps,
+                       ctx->rt_dinv, ctx->rt_r, ctx->rt_z, ctx->rt_partial);
+    hipLaunchKernelGGL(b_final_kernel, dim3(kRatSystems), dim3(kBlock), 0, ctx->stream, ctx->rt_partial, cps,
+                       ctx->rt_scb, (int)FIN_RZ);
+    hipLaunchKernelGGL(b_p_update_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->rt_scb, cps,
+                       it == 1 ? 1 : 0, ctx->rt_z, ctx->rt_p);
+    {
+      const DevCsr &m = ctx->rat_mat;
+      switch (m.L) {
+        case 4: launch_spmv_L<4>(ctx, m, ctx->rt_p, ctx->rt_Ap, 0, 0.0, nullptr, nullptr); break;
+        case 8: launch_spmv_L<8>(ctx, m, ctx->rt_p, ctx->rt_Ap, 0, 0.0, nullptr, nullptr); break;
+        case 16: launch_spmv_L<16>(ctx, m, ctx->rt_p, ctx->rt_Ap, 0, 0.0, nullptr, nullptr); break;
+        case 32: launch_spmv_L<32>(ctx, m, ctx->rt_p, ctx->rt_Ap, 0, 0.0, nullptr, nullptr); break;
+        default: launch_spmv_L<64>(ctx, m, ctx->rt_p, ctx->rt_Ap, 0, 0.0, nullptr, nullptr); break;
+      }
+    }
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->rt_p, ctx->rt_Ap,
+                       ctx->rt_partial);
+    hipLaunchKernelGGL(b_final_kernel, dim3(kRatSystems), dim3(kBlock), 0, ctx->stream, ctx->rt_partial, cps,
+                       ctx->rt_scb, (int)FIN_ALPHA);
+    hipLaunchKernelGGL(b_xr_update_dot_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->rt_scb, cps,
+                       ctx->rt_p, ctx->rt_Ap, ctx->rt_x, ctx->rt_r, ctx->rt_partial);
+    hipLaunchKernelGGL(b_final_kernel, dim3(kRatSystems), dim3(kBlock), 0, ctx->stream, ctx->rt_partial, cps,
+                       ctx->rt_scb, (int)FIN_STORE);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(sh, ctx->rt_scb, kRatSystems * kBS * sizeof(double), hipMemcpyDeviceToHost,
+                        ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    nactive = 0;
+    for (int s = 0; s < kRatSystems; ++s)
+      if (st[s] == ITERATE) {
+        its[s] = it;
+        st[s] = sc[s].check(it, std::sqrt(sh[s * kBS + B_RR]));
+        nactive += st[s] == ITERATE;
+      }
+  }
+  for (int s = 0; s < kRatSystems; ++s) {
+    ctx->rational_its += its[s];
+    if (st[s] == FAILURE) {
+      if (std::isnan(sc[s].last_value)) return ctx->err = "rational CG breakdown (NaN)", ALFD_E_BREAKDOWN;
+      if (ctx->cfg.on_inner_failure == ALFD_INNER_THROW)
+        return ctx->err = "rational-preconditioner CG did not converge", ALFD_E_NO_CONVERGENCE_INNER;
+      ctx->inner_failures++;
+    }
+  }
+  hipLaunchKernelGGL(b_combine_kernel, dim3((unsigned)cps), dim3(kBlock), 0, ctx->stream, kRatSystems, npl,
+                     ctx->rt_coef, ctx->rt_x, v1);
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
 // Preconditioner vmult on padded device block vectors.
 static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
   ctx->precond_applications++;
@@ -666,6 +792,11 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
     RC(spmv(ctx, ALFD_M, v + off[2], ctx->rhs_tmp + off[1], 1, 1.0));           // u1 + M v2
     return inner_solve(ctx, OP_AUG2, ctx->rhs_tmp, v);                          // [v0;v1] = Aug_inv (...)
   }
+  if (c.variant == ALFD_RATIONAL) {
+    // RationalPreconditioner::vmult (block diagonal, SPD): v0 = K_inv u0, v1 = rational(u1)
+    RC(inner_solve(ctx, OP_K, u + off[0], v + off[0]));
+    return rational_apply(ctx, u + off[1], v + off[1]);
+  }
   return ctx->err = "preconditioner variant not implemented yet", ALFD_E_UNSUPPORTED;
 }
 
@@ -687,6 +818,12 @@ static int system_apply(alfd_ctx *ctx, const double *x, double *y) {
     }
     RC(spmv(ctx, ALFD_CT, x + off[last], y0, 1, 1.0));
     return ALFD_OK;
+  }
+  if (c.variant == ALFD_RATIONAL) {
+    // AA = [[K, Ct],[C, 0]] (immersed_laplace.cc:596-597)
+    RC(spmv(ctx, ALFD_A, x + off[0], y + off[0], 0));
+    RC(spmv(ctx, ALFD_CT, x + off[1], y + off[0], 1, 1.0));
+    return spmv(ctx, ALFD_C, x + off[0], y + off[1], 0);
   }
   if (is_elliptic(c.variant)) {
     // elliptic_interface.cc:810-819
@@ -813,6 +950,110 @@ static int fgmres(alfd_ctx *ctx, alfd_result *out) {
   if (st != SUCCESS) {
     ctx->err = "FGMRES did not converge (SolverControl::NoConvergence)";
     return std::isnan(res) ? ALFD_E_BREAKDOWN : ALFD_E_NO_CONVERGENCE_OUTER;
+  }
+  return ALFD_OK;
+}
+
+// deal.II SolverMinRes [EXT] on device vectors (immersed_laplace.cc:629-631,
+// stokes...:1057-1064).  Vectors: u0,u1,u2 | m0,m1,m2 | v live in the Krylov arenas.
+static int minres(alfd_ctx *ctx, alfd_result *out) {
+  const alfd_config &c = ctx->cfg;
+  const int64_t N = ctx->ntot();
+  double *x = ctx->xb, *b = ctx->bb;
+  double *u0 = ctx->V, *u1 = ctx->V + N, *u2 = ctx->V + 2 * N;
+  double *m0 = ctx->Z, *m1 = ctx->Z + N, *m2 = ctx->Z + 2 * N;
+  double *v = ctx->V + 3 * N;
+  double delta[3] = {0, 0, 0}, f[2] = {0, 0}, e[2] = {0, 0};
+  double r_l2 = 0, r0 = 0, tau = 0, cc = 0, ss = 0, d_ = 0, phibar = 0;
+  int j = 1;
+  Control sc{c.outer};
+  ctx->history.clear();
+  auto dotv = [&](const double *a, const double *bb_, double *res) -> int {
+    RC(dot_async(ctx, N, a, bb_, S_TMP));
+    RC(read_scalars(ctx, S_TMP, 1));
+    *res = ctx->sc_host[S_TMP];
+    return ALFD_OK;
+  };
+  RC(system_apply(ctx, x, m0));
+  HIPC(hipMemcpyAsync(u1, m0, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  VEC_LAUNCH(sub_from_kernel, N, 24, b, u1);                       // u1 = b - A x
+  HIPC(hipMemsetAsync(v, 0, N * sizeof(double), ctx->stream));
+  RC(precond_apply(ctx, u1, v));
+  RC(dotv(v, u1, &delta[1]));
+  if (delta[1] < 0) return ctx->err = "MinRes: preconditioner not positive definite", ALFD_E_BREAKDOWN;
+  r0 = std::sqrt(delta[1]);
+  r_l2 = r0;
+  phibar = r0;
+  HIPC(hipMemsetAsync(u0, 0, N * sizeof(double), ctx->stream));
+  delta[0] = 1.0;
+  HIPC(hipMemsetAsync(ctx->Z, 0, 3 * N * sizeof(double), ctx->stream));
+  State st = sc.check(0, r_l2);
+  ctx->history.push_back(r_l2);
+  if (c.log_level >= 2 && ctx->rank == 0) std::printf("DEAL:minres::Check 0\t%.17g\n", r_l2);
+  while (st == ITERATE) {
+    if (delta[1] != 0)
+      VEC_LAUNCH(scale_kernel, N, 16, (const double *)nullptr, 0, 0, 1.0 / std::sqrt(delta[1]), v);
+    else
+      HIPC(hipMemsetAsync(v, 0, N * sizeof(double), ctx->stream));
+    RC(system_apply(ctx, v, u2));
+    VEC_LAUNCH(axpy_kernel, N, 24, (const double *)nullptr, 0, -std::sqrt(delta[1] / delta[0]), u0, u2);
+    double gamma = 0;
+    RC(dotv(u2, v, &gamma));
+    VEC_LAUNCH(axpy_kernel, N, 24, (const double *)nullptr, 0, -gamma / std::sqrt(delta[1]), u1, u2);
+    HIPC(hipMemcpyAsync(m0, v, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    RC(precond_apply(ctx, u2, v));
+    RC(dotv(v, u2, &delta[2]));
+    if (delta[2] < 0) return ctx->err = "MinRes: preconditioner not positive definite", ALFD_E_BREAKDOWN;
+    if (j == 1) {
+      d_ = gamma;
+      e[1] = std::sqrt(delta[2]);
+    }
+    if (j > 1) {
+      d_ = ss * e[0] - cc * gamma;
+      e[0] = cc * e[0] + ss * gamma;
+      f[1] = ss * std::sqrt(delta[2]);
+      e[1] = -cc * std::sqrt(delta[2]);
+    }
+    const double d = std::sqrt(d_ * d_ + delta[2]);
+    // tau_j = c_j phibar_{j-1}, phibar_j = s_j phibar_{j-1}: division-free form of deal.II's
+    // "tau *= s/c; tau *= c" (which is 0*inf when the first Lanczos coefficient is 0)
+    cc = d_ / d;
+    ss = std::sqrt(delta[2]) / d;
+    tau = cc * phibar;
+    phibar = ss * phibar;
+    VEC_LAUNCH(axpy_kernel, N, 24, (const double *)nullptr, 0, -e[0], m1, m0);
+    if (j > 1) VEC_LAUNCH(axpy_kernel, N, 24, (const double *)nullptr, 0, -f[0], m2, m0);
+    VEC_LAUNCH(scale_kernel, N, 16, (const double *)nullptr, 0, 0, 1.0 / d, m0);
+    VEC_LAUNCH(axpy_kernel, N, 24, (const double *)nullptr, 0, tau, m0, x);
+    r_l2 *= std::fabs(ss);
+    st = sc.check(j, r_l2);
+    ctx->history.push_back(r_l2);
+    if (c.log_level >= 2 && ctx->rank == 0) std::printf("DEAL:minres::Check %d\t%.17g\n", j, r_l2);
+    ++j;
+    double *t = u0;
+    u0 = u1;
+    u1 = u2;
+    u2 = t;
+    t = m2;
+    m2 = m1;
+    m1 = m0;
+    m0 = t;
+    delta[0] = delta[1];
+    delta[1] = delta[2];
+    f[0] = f[1];
+    e[0] = e[1];
+  }
+  HIPC(hipStreamSynchronize(ctx->stream));
+  out->outer_iterations = j - 1;
+  out->initial_residual = sc.initial;
+  out->last_residual = r_l2;
+  if (c.log_level >= 1 && ctx->rank == 0)
+    std::printf(st == SUCCESS ? "DEAL:minres::Convergence step %d value %.17g\n"
+                              : "DEAL:minres::Failure step %d value %.17g\n",
+                j - 1, r_l2);
+  if (st != SUCCESS) {
+    ctx->err = "MinRes did not converge (SolverControl::NoConvergence)";
+    return std::isnan(r_l2) ? ALFD_E_BREAKDOWN : ALFD_E_NO_CONVERGENCE_OUTER;
   }
   return ALFD_OK;
 }
@@ -1176,7 +1417,7 @@ static int power_iteration(alfd_ctx *ctx, int op) {
     fill(0, v);
     fill(1, v + ctx->off[1]);
   } else {
-    fill(op == OP_AUG ? 0 : 1, v);
+    fill((op == OP_AUG || op == OP_K) ? 0 : 1, v);
   }
   double lam = 0;
   for (int it = 0; it < c.cheb_power_its; ++it) {
@@ -1200,7 +1441,10 @@ static int power_iteration(alfd_ctx *ctx, int op) {
 static int setup(alfd_ctx *ctx) {
   if (!ctx->configured) return ctx->err = "alfd_configure not called", ALFD_E_NOT_SETUP;
   const alfd_config &c = ctx->cfg;
-  if (c.variant == ALFD_RATIONAL) return ctx->err = "variant not implemented yet", ALFD_E_UNSUPPORTED;
+  const bool rat = c.variant == ALFD_RATIONAL;
+  if (rat && ctx->nranks > 1) return ctx->err = "rational variant is single-rank", ALFD_E_UNSUPPORTED;
+  if (c.outer_solver == ALFD_OUTER_MINRES && c.restart < 4)
+    return ctx->err = "MinRes needs restart >= 4 (vector arena)", ALFD_E_INVALID;
   if (c.restart < 1 || c.restart > kMaxBasis - 1) return ctx->err = "restart out of range", ALFD_E_INVALID;
   const bool ell = is_elliptic(c.variant);
   if (!c.grad_div_in_A && (c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG))
@@ -1218,10 +1462,17 @@ static int setup(alfd_ctx *ctx) {
   ctx->nblocks = nblocks_of(c.variant);
   const int last = ctx->nblocks - 1;
   if (!ctx->mat[ALFD_A].present || !ctx->mat[ALFD_CT].present || !ctx->mat[ALFD_C].present ||
-      !ctx->diag[ALFD_INVW])
+      (!ctx->diag[ALFD_INVW] && !rat))
     return ctx->err = "A, CT (and C) and INVW must be set", ALFD_E_NOT_SETUP;
   ctx->n[0] = ctx->mat[ALFD_A].nrows;
   ctx->n[last] = ctx->mat[ALFD_C].nrows;
+  if (rat) {
+    const alfd_ctx::HostCsr &K = ctx->h_K, &M = ctx->h_M;
+    if (K.rp.empty() || M.rp.empty()) return ctx->err = "KIMM and M must be set for the rational variant", ALFD_E_NOT_SETUP;
+    if (K.nrows != ctx->n[1] || M.nrows != ctx->n[1] || K.col != M.col || K.rp != M.rp)
+      return ctx->err = "KIMM and M must share one sparsity pattern (matrix.add)", ALFD_E_INVALID;
+    if (!(c.rho_bound > 0)) return ctx->err = "rho_bound must be positive", ALFD_E_INVALID;
+  }
   if (ell) {
     if (!ctx->mat[ALFD_A2].present || !ctx->mat[ALFD_M].present)
       return ctx->err = "A2 and M must be set for the elliptic-interface variants", ALFD_E_NOT_SETUP;
@@ -1234,7 +1485,7 @@ static int setup(alfd_ctx *ctx) {
       return ctx->err = "BT, B, MP and MP_LUMPED_INV must be set for the Stokes variants", ALFD_E_NOT_SETUP;
     ctx->n[1] = ctx->mat[ALFD_B].nrows;
   }
-  if (ctx->mat[ALFD_CT].nrows != ctx->n[0] || ctx->diag_n[ALFD_INVW] != ctx->n[last])
+  if (ctx->mat[ALFD_CT].nrows != ctx->n[0] || (!rat && ctx->diag_n[ALFD_INVW] != ctx->n[last]))
     return ctx->err = "inconsistent block sizes", ALFD_E_INVALID;
   ctx->nmax = 0;
   for (int b = 0; b < ctx->nblocks; ++b) {
@@ -1272,10 +1523,93 @@ static int setup(alfd_ctx *ctx) {
   RC(ws_alloc_zero(ctx, &ctx->xb, N));
   RC(ws_alloc_zero(ctx, &ctx->bb, N));
   RC(ws_alloc_zero(ctx, &ctx->io, N));
-  for (int k = 0; k < 4; ++k) ctx->lam_max[k] = 0;
+  for (int k = 0; k < 6; ++k) ctx->lam_max[k] = 0;
+  const bool cheb = c.inner_prec == ALFD_PREC_CHEBYSHEV;
+  if (rat) {
+    // K_inv: Jacobi / Chebyshev-Jacobi CG on K itself
+    RC(ws_alloc_zero(ctx, &ctx->dinv_k, n0p));
+    {
+      const DevCsr &A = ctx->mat[ALFD_A];
+      const int grid = grid_for_rows(A.nrows, A.L);
+#define ALFD_DIAG(LL)                                                                                   \
+  hipLaunchKernelGGL((extract_diag_kernel<LL>), dim3(grid), dim3(kBlock), 0, ctx->stream, A.nrows, A.rp, \
+                     A.col, A.val, ctx->dA)
+      switch (A.L) {
+        case 4: ALFD_DIAG(4); break;
+        case 8: ALFD_DIAG(8); break;
+        case 16: ALFD_DIAG(16); break;
+        case 32: ALFD_DIAG(32); break;
+        default: ALFD_DIAG(64); break;
+      }
+#undef ALFD_DIAG
+      hipLaunchKernelGGL(inv_diag_kernel, dim3((unsigned)((ctx->n[0] + 255) / 256)), dim3(256), 0, ctx->stream,
+                         ctx->n[0], ctx->dA, ctx->dinv_k);
+    }
+    if (cheb) RC(power_iteration(ctx, OP_K));
+    // block-diagonal matrix of the 21 immersed systems, segment s at rows/cols s*npl
+    const alfd_ctx::HostCsr &K = ctx->h_K, &M = ctx->h_M;
+    const int64_t n1 = ctx->n[1], npl = pad_chunk(n1), nnz1 = K.rp[n1];
+    std::vector<int64_t> rp((size_t)npl * kRatSystems + 1, 0);
+    std::vector<int32_t> col((size_t)nnz1 * kRatSystems);
+    std::vector<double> val((size_t)nnz1 * kRatSystems);
+    for (int sidx = 0; sidx < kRatSystems; ++sidx) {
+      const double sh = sidx < 20 ? -(c.rho_bound * kRatPoles[sidx]) : 0.0;  // matrix.add(-rho p_i, M)
+      for (int64_t r = 0; r < npl; ++r) {
+        const int64_t gr = (int64_t)sidx * npl + r;
+        rp[gr + 1] = rp[gr] + (r < n1 ? K.rp[r + 1] - K.rp[r] : 0);
+      }
+      for (int64_t k = 0; k < nnz1; ++k) {
+        col[(size_t)sidx * nnz1 + k] = (int32_t)(K.col[k] + sidx * npl);
+        val[(size_t)sidx * nnz1 + k] = sidx < 20 ? std::fma(sh, M.val[k], K.val[k]) : M.val[k];
+      }
+    }
+    {
+      // upload through the generic path into a scratch slot object
+      DevCsr keep = ctx->mat[ALFD_KIMM];
+      RC(upload_matrix(ctx, ALFD_KIMM, npl * kRatSystems, npl * kRatSystems, rp.data(), col.data(), val.data()));
+      ctx->rat_mat = ctx->mat[ALFD_KIMM];
+      ctx->mat[ALFD_KIMM] = keep;
+    }
+    const int64_t nt = npl * kRatSystems;
+    RC(ws_alloc_zero(ctx, &ctx->rt_r, nt));
+    RC(ws_alloc_zero(ctx, &ctx->rt_z, nt));
+    RC(ws_alloc_zero(ctx, &ctx->rt_p, nt));
+    RC(ws_alloc_zero(ctx, &ctx->rt_Ap, nt));
+    RC(ws_alloc_zero(ctx, &ctx->rt_x, nt));
+    RC(ws_alloc_zero(ctx, &ctx->rt_dinv, nt));
+    RC(ws_alloc_zero(ctx, &ctx->rt_partial, nt / kChunk + 1));
+    RC(ws_alloc_zero(ctx, &ctx->rt_scb, kRatSystems * kBS));
+    RC(ws_alloc_zero(ctx, &ctx->rt_coef, kRatSystems));
+    if (ctx->rt_scb_host) hipHostFree(ctx->rt_scb_host), ctx->rt_scb_host = nullptr;
+    HIPC(hipHostMalloc((void **)&ctx->rt_scb_host, kRatSystems * kBS * sizeof(double)));
+    {
+      // 1/diag of the shifted systems (same fma as the values above), 1 for the
+      // unpreconditioned mass solve, 0 in the padding
+      std::vector<double> dinv((size_t)nt, 0.0);
+      for (int sidx = 0; sidx < kRatSystems; ++sidx) {
+        const double sh = sidx < 20 ? -(c.rho_bound * kRatPoles[sidx]) : 0.0;
+        for (int64_t r = 0; r < n1; ++r) {
+          double d = 1.0;
+          if (sidx < 20)
+            for (int64_t k = K.rp[r]; k < K.rp[r + 1]; ++k)
+              if (K.col[k] == r) d = 1.0 / std::fma(sh, M.val[k], K.val[k]);
+          dinv[(size_t)sidx * npl + r] = d;
+        }
+      }
+      HIPC(hipMemcpyAsync(ctx->rt_dinv, dinv.data(), nt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipStreamSynchronize(ctx->stream));
+    }
+    double coef[kRatSystems];
+    for (int sidx = 0; sidx < 20; ++sidx) coef[sidx] = c.rho_bound * kRatRes[sidx + 1];
+    coef[20] = kRatRes[0];
+    HIPC(hipMemcpyAsync(ctx->rt_coef, coef, sizeof(coef), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    ctx->lambda_max = ctx->lam_max[OP_K];
+    ctx->is_setup = true;
+    return ALFD_OK;
+  }
   // diag(Aug) = diag(A) + gamma sum_k w_k Ct_ik^2 (no product matrix is formed)
   RC(diag_plus(ctx, ALFD_A, ALFD_CT, c.gamma, ctx->n[0], ctx->dinv_aug));
-  const bool cheb = c.inner_prec == ALFD_PREC_CHEBYSHEV;
   if (ell) {
     // diag(A22_aug) = diag(A2) + gamma2 sum_k w_k M_ik^2
     RC(ws_alloc_zero(ctx, &ctx->dinv_a22, pad_chunk(ctx->n[1])));
@@ -1320,6 +1654,7 @@ static int to_host(alfd_ctx *ctx, const double *dev, double *const *blocks) {
 static void reset_stats(alfd_ctx *ctx) {
   ctx->inner_its = ctx->mp_its = 0;
   ctx->inner_failures = ctx->precond_applications = 0;
+  ctx->rational_its = 0;
 }
 static void fill_result(alfd_ctx *ctx, alfd_result *res, int status) {
   res->status = status;
@@ -1328,6 +1663,7 @@ static void fill_result(alfd_ctx *ctx, alfd_result *res, int status) {
   res->inner_failures = ctx->inner_failures;
   res->precond_applications = ctx->precond_applications;
   res->lambda_max = ctx->lambda_max;
+  res->rational_iterations = ctx->rational_its;
 }
 
 }  // namespace alfd
@@ -1394,6 +1730,7 @@ int alfd_destroy(alfd_ctx_t ctx) {
   for (void *p : ctx->ws_allocs) hipFree(p);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->sc_host) hipHostFree(ctx->sc_host);
+  if (ctx->rt_scb_host) hipHostFree(ctx->rt_scb_host);
   if (ctx->nccl) ncclCommDestroy(ctx->nccl);
   hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1478,6 +1815,15 @@ int alfd_set_matrix(alfd_ctx_t ctx, int slot, int64_t nrows, int64_t ncols, cons
   if (ctx->nranks > 1 && ctx->nblocks == 0)
     return ctx->err = "alfd_set_partition must precede alfd_set_matrix", ALFD_E_INVALID;
   RC(upload_matrix(ctx, slot, nrows, ncols, row_ptr, col, val));
+  if ((slot == ALFD_M || slot == ALFD_KIMM) && nnz <= (int64_t)1 << 26) {
+    // the rational preconditioner builds its 21 shifted systems from these on the host
+    alfd_ctx::HostCsr &h = slot == ALFD_M ? ctx->h_M : ctx->h_K;
+    h.nrows = nrows;
+    h.ncols = ncols;
+    h.rp.assign(row_ptr, row_ptr + nrows + 1);
+    h.col.assign(col, col + nnz);
+    h.val.assign(val, val + nnz);
+  }
   // single rank: the transposed operators are derived on upload, like
   // transpose_operator(Ct) (stokes...:927); an explicit upload later overrides.
   if (ctx->nranks == 1) {
@@ -1519,6 +1865,9 @@ void alfd_default_config(alfd_config *c, int variant) {
   c->cheb_eig_ratio = 30.0;
   c->cheb_safety = 1.2;
   c->log_level = 0;
+  c->outer_solver = variant == ALFD_RATIONAL ? ALFD_OUTER_MINRES : ALFD_OUTER_FGMRES;
+  c->rho_bound = 0.0;
+  c->rational = {ALFD_CTRL_ABS, 2000, 1e-14, 0.0};
 }
 
 int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg) {
@@ -1566,6 +1915,8 @@ int alfd_augment_rhs(alfd_ctx_t ctx, double *const *rhs) {
   CHECK_CTX();
   CHECK_SETUP();
   if (!rhs) return ALFD_E_INVALID;
+  if (!ctx->diag[ALFD_INVW] || ctx->cfg.variant == ALFD_RATIONAL)
+    return ctx->err = "rhs augmentation applies to the AL variants only", ALFD_E_UNSUPPORTED;
   const int last = ctx->nblocks - 1;
   RC(to_device(ctx, rhs, ctx->bb));
   VEC_LAUNCH(pmul_scale_kernel, pad_chunk(ctx->n[last]), 24, 1.0, ctx->diag[ALFD_INVW],
@@ -1597,7 +1948,7 @@ int alfd_solve_resident(alfd_ctx_t ctx, alfd_result *res) {
   HIPC(hipMemcpyAsync(ctx->xb, ctx->io, ctx->ntot() * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = fgmres(ctx, res);
+  const int rc = ctx->cfg.outer_solver == ALFD_OUTER_MINRES ? minres(ctx, res) : fgmres(ctx, res);
   hipStreamSynchronize(ctx->stream);
   res->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   flush_timers(ctx);

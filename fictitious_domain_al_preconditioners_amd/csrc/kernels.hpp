@@ -610,6 +610,149 @@ __global__ __launch_bounds__(kBlock) void cheb_step_kernel(double c1, double c2,
   }
 }
 
+// ---- batched lock-step CG (RationalPreconditioner: 21 independent SPD solves on
+// the immersed matrices, rational_preconditioner.h:41-56).  All systems advance
+// together, one workgroup-chunk per 4096 entries; segment s owns chunks
+// [s*cps, (s+1)*cps) and its own scalar row scb[s*kBS ..].  A system that has
+// met its stop rule is frozen (active flag 0): its x, r, p are never touched
+// again, so every system performs exactly the arithmetic of a stand-alone CG.
+constexpr int kBS = 8;  // scalars per system: RZ, RZ_OLD, PAP, ALPHA, NALPHA, BETA, RR, ACTIVE
+enum { B_RZ = 0, B_RZ_OLD = 1, B_PAP = 2, B_ALPHA = 3, B_NALPHA = 4, B_BETA = 5, B_RR = 6, B_ACTIVE = 7 };
+
+__global__ __launch_bounds__(kBlock) void b_jacobi_dot_kernel(const double *__restrict__ scb, int cps,
+                                                              const double *__restrict__ d,
+                                                              const double *__restrict__ r,
+                                                              double *__restrict__ z,
+                                                              double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  const int seg = blockIdx.x / cps;
+  if (scb[seg * kBS + B_ACTIVE] == 0.0) return;
+  double acc = 0.0;
+  ALFD_FOR_PAIRS(i) {
+    const double2 dv = ld2(d, i), rv = ld2(r, i);
+    double2 zv;
+    zv.x = dv.x * rv.x;
+    zv.y = dv.y * rv.y;
+    st2(z, i, zv);
+    acc = fma(rv.x, zv.x, acc);
+    acc = fma(rv.y, zv.y, acc);
+  }
+  const double sum = block_reduce_256(acc, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = sum;
+}
+
+// one workgroup per system: reduce its cps chunk partials, then the CG scalar update
+__global__ __launch_bounds__(kBlock) void b_final_kernel(const double *__restrict__ partial, int cps,
+                                                         double *__restrict__ scb, int fin) {
+  __shared__ double lds4[4];
+  const int seg = blockIdx.x;
+  double *sc = scb + seg * kBS;
+  if (sc[B_ACTIVE] == 0.0) return;
+  const double *p = partial + (int64_t)seg * cps;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < cps; i += kBlock) acc = acc + p[i];
+  const double s = block_reduce_256(acc, lds4);
+  if (threadIdx.x == 0) {
+    if (fin == FIN_STORE) {
+      sc[B_RR] = s;
+    } else if (fin == FIN_ALPHA) {
+      sc[B_PAP] = s;
+      const double a = sc[B_RZ] / s;
+      sc[B_ALPHA] = a;
+      sc[B_NALPHA] = -a;
+    } else {
+      const double old = sc[B_RZ];
+      sc[B_RZ_OLD] = old;
+      sc[B_RZ] = s;
+      sc[B_BETA] = s / old;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void b_p_update_kernel(const double *__restrict__ scb, int cps, int first,
+                                                            const double *__restrict__ z,
+                                                            double *__restrict__ p) {
+  const int seg = blockIdx.x / cps;
+  if (scb[seg * kBS + B_ACTIVE] == 0.0) return;
+  const double beta = first ? 0.0 : scb[seg * kBS + B_BETA];
+  ALFD_FOR_PAIRS(i) {
+    const double2 zv = ld2(z, i);
+    if (first) {
+      st2(p, i, zv);
+    } else {
+      double2 pv = ld2(p, i);
+      pv.x = fma(beta, pv.x, zv.x);
+      pv.y = fma(beta, pv.y, zv.y);
+      st2(p, i, pv);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void b_xr_update_dot_kernel(const double *__restrict__ scb, int cps,
+                                                                 const double *__restrict__ p,
+                                                                 const double *__restrict__ Ap,
+                                                                 double *__restrict__ x,
+                                                                 double *__restrict__ r,
+                                                                 double *__restrict__ partial) {
+  __shared__ double lds4[4];
+  const int seg = blockIdx.x / cps;
+  if (scb[seg * kBS + B_ACTIVE] == 0.0) return;
+  const double a = scb[seg * kBS + B_ALPHA], na = scb[seg * kBS + B_NALPHA];
+  double acc = 0.0;
+  ALFD_FOR_PAIRS(i) {
+    const double2 pv = ld2(p, i), av = ld2(Ap, i);
+    double2 xv = ld2(x, i), rv = ld2(r, i);
+    xv.x = fma(a, pv.x, xv.x);
+    xv.y = fma(a, pv.y, xv.y);
+    rv.x = fma(na, av.x, rv.x);
+    rv.y = fma(na, av.y, rv.y);
+    st2(x, i, xv);
+    st2(r, i, rv);
+    acc = fma(rv.x, rv.x, acc);
+    acc = fma(rv.y, rv.y, acc);
+  }
+  const double s = block_reduce_256(acc, lds4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// r_s = b for every system s (one padded copy of the rhs per segment)
+__global__ __launch_bounds__(kBlock) void b_replicate_kernel(int cps, const double *__restrict__ b,
+                                                             double *__restrict__ r) {
+  const int64_t lbase = (int64_t)(blockIdx.x % cps) * kChunk;
+  const int64_t gbase = (int64_t)blockIdx.x * kChunk;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t o = e * 512 + 2 * threadIdx.x;
+    st2(r, gbase + o, ld2(b, lbase + o));
+  }
+}
+
+// out = sum_s coef[s] * X_s, accumulated s = 0..nseg-1 as out = out + coef*x
+// (rational_preconditioner.h:59-62)
+__global__ __launch_bounds__(kBlock) void b_combine_kernel(int nseg, int64_t seglen,
+                                                           const double *__restrict__ coef,
+                                                           const double *__restrict__ X,
+                                                           double *__restrict__ out) {
+  ALFD_FOR_PAIRS(i) {
+    double2 a;
+    a.x = 0.0;
+    a.y = 0.0;
+    for (int s = 0; s < nseg; ++s) {
+      const double c = coef[s];
+      const double2 v = ld2(X + (int64_t)s * seglen, i);
+      a.x = a.x + c * v.x;
+      a.y = a.y + c * v.y;
+    }
+    st2(out, i, a);
+  }
+}
+
+// dinv[i] = 1 / dA[i] (rows < n)
+__global__ void inv_diag_kernel(int64_t n, const double *__restrict__ dA, double *__restrict__ dinv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dinv[i] = 1.0 / dA[i];
+}
+
 // ---- setup kernels
 // dA[r] = A_rr (exact copy, no arithmetic); diag column = r + row_offset, and
 // locally that is column (r) when the matrix's local columns come first.

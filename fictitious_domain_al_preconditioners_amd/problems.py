@@ -172,6 +172,12 @@ class SyntheticProblem:
         m = self.mats["M"].to_scipy()
         return 1.0 / np.asarray(m.multiply(m.T).sum(axis=1)).ravel()
 
+    def rho_bound(self) -> float:
+        """||A_Gamma||_inf / min_i M_ii (immersed_laplace.cc:609-614)."""
+        k = self.mats["K"]
+        rows = np.add.reduceat(np.abs(k.val), k.row_ptr[:-1])
+        return float(rows.max() / self.mats["M"].diagonal().min())
+
     def mp_lumped_inv(self) -> np.ndarray:
         """1 / (Mp 1)_i  (stokes_immersed_boundary.cc:946-954)."""
         mp = self.mats["Mp"]

@@ -304,6 +304,13 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config) -> Context:
     ctx.set_matrix(_abi.A, pb.mats["A"])
     ctx.set_matrix(_abi.CT, pb.mats["Ct"])
     ctx.set_matrix(_abi.C_, pb.mats["C"])
+    if cfg.variant == _abi.RATIONAL:
+        # rational branch (immersed_laplace.cc:585-631): K, Ct, immersed stiffness and mass
+        ctx.set_matrix(_abi.M, pb.mats["M"])
+        ctx.set_matrix(_abi.KIMM, pb.mats["K"])
+        ctx.configure(cfg)
+        ctx.setup(pb.block_sizes)
+        return ctx
     if "A2" in pb.mats:
         # elliptic interface: W^-1 = 1/(M^2)_ii (utilities.h:348-374, elliptic_interface.cc:726)
         ctx.set_matrix(_abi.A2, pb.mats["A2"])
@@ -372,6 +379,11 @@ class BlockTriangularALPreconditionerModified(_ALPreconditionerBase):
     variant = _abi.AL_ELL_MODIFIED
 
 
+class RationalPreconditioner(_ALPreconditionerBase):
+    """rational_preconditioner.h:12-99."""
+    variant = _abi.RATIONAL
+
+
 class SystemOperator:
     """The block_operator AA (stokes_immersed_boundary.cc:1000-1003)."""
 
@@ -382,6 +394,27 @@ class SystemOperator:
         out = self.ctx.system_apply(src)
         for d, o in zip(dst, out):
             d[...] = o
+
+
+class SolverMinRes:
+    """SolverMinRes<BlockVector<double>> (immersed_laplace.cc:629-631, stokes...:1057-1064):
+    the context must be configured with outer_solver = OUTER_MINRES."""
+
+    def __init__(self, ctx: Context):
+        if ctx.cfg is None or ctx.cfg.outer_solver != _abi.OUTER_MINRES:
+            raise ValueError("context is not configured for MinRes")
+        self.ctx = ctx
+        self.last_result = None
+
+    def solve(self, A, x, b, P):
+        if A.ctx is not self.ctx or P.ctx is not self.ctx:
+            raise ValueError("operator, preconditioner and solver must share one context")
+        sol, self.last_result = self.ctx.solve(b, x0=x)
+        for d, o in zip(x, sol):
+            d[...] = o
+
+    def last_step(self):
+        return self.last_result.outer_iterations
 
 
 class SolverFGMRES:

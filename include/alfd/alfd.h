@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 1
+#define ALFD_ABI_VERSION 2
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -114,6 +114,12 @@ enum alfd_inner_prec { ALFD_PREC_IDENTITY = 0, ALFD_PREC_JACOBI = 1, ALFD_PREC_C
  * Gram-Schmidt; >= 9.6 classical Gram-Schmidt variants. */
 enum alfd_orthogonalization { ALFD_ORTH_MGS = 0, ALFD_ORTH_CGS = 1, ALFD_ORTH_CGS2 = 2 };
 
+/* Outer Krylov method: SolverFGMRES (stokes...:1067) or SolverMinRes
+ * (stokes...:1057-1064 with the diagonal SPD preconditioner; immersed_laplace.cc:629-631
+ * with the rational preconditioner).  MinRes needs a symmetric system and an SPD
+ * preconditioner, i.e. ALFD_AL_STOKES_DIAG or ALFD_RATIONAL. */
+enum alfd_outer_solver { ALFD_OUTER_FGMRES = 0, ALFD_OUTER_MINRES = 1 };
+
 /* What to do when an inner CG hits max_steps: the reference throws
  * SolverControl::NoConvergence (THROW); ACCEPT keeps the last iterate. */
 enum alfd_inner_failure_policy { ALFD_INNER_THROW = 0, ALFD_INNER_ACCEPT = 1 };
@@ -136,7 +142,10 @@ typedef struct alfd_config {
   double cheb_eig_ratio;      /* lambda_min = lambda_max / ratio */
   double cheb_safety;         /* lambda_max *= safety (deal.II uses 1.2) */
   int32_t log_level;          /* 0 silent; 1 result lines; 2 per-iteration "Check" lines */
-  int32_t reserved;
+  int32_t outer_solver;       /* enum alfd_outer_solver */
+  /* ALFD_RATIONAL only (rational_preconditioner.h): */
+  double rho_bound;           /* ||A_Gamma||_inf / min_i M_ii, immersed_laplace.cc:609-614 */
+  alfd_control rational;      /* SolverControl(2000, 1e-14) of the 21 immersed solves, :34 */
 } alfd_config;
 
 typedef struct alfd_result {
@@ -150,6 +159,7 @@ typedef struct alfd_result {
   int32_t precond_applications;
   double solve_seconds;       /* wall time inside alfd_solve, device-synchronised */
   double lambda_max;          /* Chebyshev: estimated lambda_max(D^-1 Aug) incl. safety */
+  int64_t rational_iterations;/* total CG iterations of the 21 immersed solves (ALFD_RATIONAL) */
 } alfd_result;
 
 typedef struct alfd_ctx *alfd_ctx_t;

@@ -220,8 +220,11 @@ struct Problem {
   int64_t off[ALFD_MAX_BLOCKS + 1] = {0, 0, 0, 0};  // padded offsets
   alfd_config cfg;
   // setup products
-  std::vector<double> dinv_aug, dinv_a22, dinv_aug2;  // 1/diag of the inner operators
-  double lam_max[4] = {0, 0, 0, 0};                   // per inner operator kind
+  std::vector<double> dinv_aug, dinv_a22, dinv_aug2, dinv_k;  // 1/diag of the inner operators
+  double lam_max[6] = {0, 0, 0, 0, 0, 0};             // per inner operator kind
+  std::vector<Csr> shifted;                           // A_Gamma - rho p_i M (rational_preconditioner.h:42-45)
+  std::vector<std::vector<double>> shifted_dinv;
+  int64_t rational_its = 0;
   double lambda_max = 0;
   // stats
   int64_t inner_its = 0, mp_its = 0;
@@ -271,17 +274,24 @@ static void transpose_into(const Csr &a, Csr &t) {
 // kind 3: the 2x2 block [[A11_aug, A12_aug],[A21_aug, A22_aug]] on [x0 | pad | x1]
 //         (elliptic_interface.cc:927-929), with s = C x0 - M x1, t = w .* s:
 //           y0 = A x0 + gamma Ct t ,  y1 = A2 x1 - gamma2 M t
-enum { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3 };
+// kind 4: K x = A x (no augmentation; K_inv of the rational branch, immersed_laplace.cc:617-620)
+// kind 5: an explicit matrix on block 1 (the shifted immersed systems / the immersed mass)
+enum { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3, OP_K = 4, OP_MAT = 5 };
 
 struct InnerOp {
   Problem &P;
   int kind;
   std::vector<double> t;
-  int64_t n() const { return kind == OP_AUG ? P.n[0] : kind == OP_AUG2 ? P.off[2] : P.n[1]; }
-  int blk() const { return kind == OP_AUG ? 0 : kind == OP_AUG2 ? -1 : 1; }
+  const Csr *mat = nullptr;
+  int64_t n() const { return (kind == OP_AUG || kind == OP_K) ? P.n[0] : kind == OP_AUG2 ? P.off[2] : P.n[1]; }
+  int blk() const { return (kind == OP_AUG || kind == OP_K) ? 0 : kind == OP_AUG2 ? -1 : 1; }
   void operator()(const double *x, double *y) {
     const double *w = P.diag[ALFD_INVW];
-    if (kind == OP_AUG) {
+    if (kind == OP_K) {
+      spmv(P.mat[ALFD_A], x, y, 0, 0.0);
+    } else if (kind == OP_MAT) {
+      spmv(*mat, x, y, 0, 0.0);
+    } else if (kind == OP_AUG) {
       const Csr &C = P.mat[ALFD_C];
       spmv(P.mat[ALFD_A], x, y, 0, 0.0);
       t.resize(C.nrows);
@@ -420,7 +430,8 @@ static State pcg(const Problem &P, InnerOp &op, Prec &prec, const alfd_control &
 
 // dinv / lambda of the inner operator `kind`
 static const double *op_dinv(const Problem &P, int kind) {
-  return kind == OP_AUG ? P.dinv_aug.data() : kind == OP_A22 ? P.dinv_a22.data() : P.dinv_aug2.data();
+  return kind == OP_AUG ? P.dinv_aug.data() : kind == OP_A22 ? P.dinv_a22.data()
+         : kind == OP_K ? P.dinv_k.data() : P.dinv_aug2.data();
 }
 
 static int inner_solve(Problem &P, int kind, const double *b, double *x) {
@@ -454,6 +465,7 @@ static int inner_solve(Problem &P, int kind, const double *b, double *x) {
   return ALFD_OK;
 }
 
+static void rational_setup(Problem &P);
 static bool is_elliptic(int v) { return v == ALFD_AL_ELL_IDEAL || v == ALFD_AL_ELL_MODIFIED; }
 
 // diagonals of the inner operators and lambda_max(D^-1 Op) by power iteration
@@ -502,10 +514,21 @@ static void power_iteration(Problem &P, int kind) {
 
 static void setup(Problem &P) {
   const double *w = P.diag[ALFD_INVW];
+  for (int k = 0; k < 6; ++k) P.lam_max[k] = 0.0;
+  const bool cheb = P.cfg.inner_prec == ALFD_PREC_CHEBYSHEV;
+  if (P.cfg.variant == ALFD_RATIONAL) {
+    const Csr &A = P.mat[ALFD_A];
+    P.dinv_k.assign(P.n[0], 1.0);
+    for (int64_t i = 0; i < P.n[0]; ++i)
+      for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k)
+        if (A.col[k] == i) P.dinv_k[i] = 1.0 / A.val[k];
+    if (cheb) power_iteration(P, OP_K);
+    rational_setup(P);
+    P.lambda_max = P.lam_max[OP_K];
+    return;
+  }
   P.dinv_aug.assign(P.n[0], 0.0);
   diag_plus(P.mat[ALFD_A], P.mat[ALFD_CT], w, P.cfg.gamma, P.n[0], P.dinv_aug.data());
-  for (int k = 0; k < 4; ++k) P.lam_max[k] = 0.0;
-  const bool cheb = P.cfg.inner_prec == ALFD_PREC_CHEBYSHEV;
   if (is_elliptic(P.cfg.variant)) {
     P.dinv_a22.assign(P.n[1], 0.0);
     diag_plus(P.mat[ALFD_A2], P.mat[ALFD_M], w, P.cfg.gamma2, P.n[1], P.dinv_a22.data());
@@ -522,6 +545,69 @@ static void setup(Problem &P) {
     power_iteration(P, OP_AUG);
   }
   P.lambda_max = P.lam_max[is_elliptic(P.cfg.variant) && P.cfg.variant == ALFD_AL_ELL_IDEAL ? OP_AUG2 : OP_AUG];
+}
+
+// ---- RationalPreconditioner (rational_preconditioner.h:29-63) ----------------
+// numeric constants of the reference's rational approximation (:70-93)
+static const double kRatRes[21] = {
+    1.1133752551375149e+01,  -4.5192561264009555e+02, -5.4280235488093114e+00, -6.6119823627983498e-01,
+    -1.5483255874020074e-01, -4.8435293477731435e-02, -1.7569986796633446e-02, -6.9011933591631392e-03,
+    -2.8275585395562131e-03, -1.1823861060446343e-03, -4.9806992558149195e-04, -2.0975776516702764e-04,
+    -8.7959042415258930e-05, -3.6650480089224726e-05, -1.5149104182285630e-05, -6.1866179967421625e-06,
+    -2.4691626461139533e-06, -9.3898594542244485e-07, -3.2099152020952601e-07, -8.4169497470931466e-08,
+    -7.7616172944516437e-09};
+static const double kRatPoles[20] = {
+    -4.9917060842594275e+01, -5.2698715191349796e+00, -1.7156755741861143e+00, -7.5569620064292298e-01,
+    -3.7811376547012854e-01, -2.0130525955937850e-01, -1.1058502730933521e-01, -6.1664070123493613e-02,
+    -3.4578652087400880e-02, -1.9394206381182760e-02, -1.0845568864180035e-02, -6.0343457447149737e-03,
+    -3.3328397814762593e-03, -1.8198589302273998e-03, -9.7434812604726647e-04, -5.0332017175529794e-04,
+    -2.4317839761161207e-04, -1.0297057301403903e-04, -3.2227929557637293e-05, -3.3293811779427837e-06};
+
+static void rational_setup(Problem &P) {
+  const Csr &K = P.mat[ALFD_KIMM], &M = P.mat[ALFD_M];
+  const int64_t n = K.nrows, nnz = K.nnz();
+  P.shifted.assign(20, Csr());
+  P.shifted_dinv.assign(21, std::vector<double>(n, 1.0));  // entry 20: identity (M solve is unpreconditioned)
+  for (int i = 0; i < 20; ++i) {
+    Csr &S = P.shifted[i];
+    S.nrows = K.nrows;
+    S.ncols = K.ncols;
+    S.rp = K.rp;
+    S.col = K.col;
+    S.own_val.resize(nnz);
+    const double sh = -(P.cfg.rho_bound * kRatPoles[i]);  // matrix.add(-rho_bound * poles[i-1], M)
+    for (int64_t k = 0; k < nnz; ++k) S.own_val[k] = std::fma(sh, M.val[k], K.val[k]);
+    S.val = S.own_val.data();
+    S.L = K.L;
+    S.V = K.V;
+    for (int64_t r = 0; r < n; ++r)
+      for (int64_t k = S.rp[r]; k < S.rp[r + 1]; ++k)
+        if (S.col[k] == r) P.shifted_dinv[i][r] = 1.0 / S.val[k];
+  }
+}
+
+// v1 = sum_i rho res_i (A_Gamma - rho p_i M)^-1 u1 + res_0 M^-1 u1, accumulated in
+// the order of rational_preconditioner.h:51-62 (poles first, the mass term last)
+static int rational_apply(Problem &P, const double *u1, double *v1) {
+  const int64_t n = P.n[1];
+  std::vector<double> x(n);
+  std::fill(v1, v1 + n, 0.0);
+  for (int i = 0; i <= 20; ++i) {
+    InnerOp op{P, OP_MAT, {}, i < 20 ? &P.shifted[i] : &P.mat[ALFD_M]};
+    DiagPrec pr{P.shifted_dinv[i].data()};
+    int its = 0;
+    double res = 0;
+    State st = pcg(P, op, pr, P.cfg.rational, u1, x.data(), its, res, P.cfg.log_level, "rat");
+    P.rational_its += its;
+    if (st == FAILURE) {
+      if (std::isnan(res)) return ALFD_E_BREAKDOWN;
+      if (P.cfg.on_inner_failure == ALFD_INNER_THROW) return ALFD_E_NO_CONVERGENCE_INNER;
+      P.inner_failures++;
+    }
+    const double c = i < 20 ? P.cfg.rho_bound * kRatRes[i + 1] : kRatRes[0];
+    for (int64_t e = 0; e < n; ++e) v1[e] = v1[e] + c * x[e];
+  }
+  return ALFD_OK;
 }
 
 // ------------------------------------------------- preconditioner vmult
@@ -589,6 +675,12 @@ static int precond_apply(Problem &P, const double *u, double *v) {
     spmv(P.mat[ALFD_M], v2, uu.data() + P.off[1], 1, 1.0);
     return inner_solve(P, OP_AUG2, uu.data(), v);
   }
+  if (c.variant == ALFD_RATIONAL) {
+    // RationalPreconditioner::vmult, rational_preconditioner.h:29-63 (block diagonal, SPD)
+    int rc = inner_solve(P, OP_K, u + P.off[0], v + P.off[0]);   // v0 = K_inv u0
+    if (rc != ALFD_OK) return rc;
+    return rational_apply(P, u + P.off[1], v + P.off[1]);
+  }
   return ALFD_E_UNSUPPORTED;
 }
 
@@ -612,6 +704,13 @@ static int system_apply(Problem &P, const double *x, double *y) {
       spmv(P.mat[ALFD_B], x0, y + P.off[1], 0, 0.0);    // y1 = B x0
     }
     spmv(P.mat[ALFD_CT], xl, y0, 1, 1.0);               // + Ct x_lambda
+    return ALFD_OK;
+  }
+  if (c.variant == ALFD_RATIONAL) {
+    // AA = [[K, Ct],[C, 0]] (immersed_laplace.cc:596-597): no augmentation
+    spmv(P.mat[ALFD_A], x + P.off[0], y + P.off[0], 0, 0.0);
+    spmv(P.mat[ALFD_CT], x + P.off[1], y + P.off[0], 1, 1.0);
+    spmv(P.mat[ALFD_C], x + P.off[0], y + P.off[1], 0, 0.0);
     return ALFD_OK;
   }
   if (is_elliptic(c.variant)) {
@@ -747,6 +846,105 @@ static int fgmres(Problem &P, const double *b, double *x, alfd_result *out,
   return ALFD_OK;
 }
 
+// deal.II SolverMinRes [EXT] (preconditioned MINRES with the Lanczos three-term
+// recurrence; r_l2 is the preconditioned residual estimate the stop rule sees).
+// Used at immersed_laplace.cc:629-631 and stokes...:1057-1064.
+static int minres(Problem &P, const double *b, double *x, alfd_result *out, std::vector<double> &history) {
+  const alfd_config &c = P.cfg;
+  const int64_t N = P.ntot();
+  std::vector<double> U[3], Mv[3], v(N, 0.0);
+  for (int i = 0; i < 3; ++i) U[i].assign(N, 0.0), Mv[i].assign(N, 0.0);
+  double *u0 = U[0].data(), *u1 = U[1].data(), *u2 = U[2].data();
+  double *m0 = Mv[0].data(), *m1 = Mv[1].data(), *m2 = Mv[2].data();
+  double delta[3] = {0, 0, 0}, f[2] = {0, 0}, e[2] = {0, 0};
+  double r_l2 = 0, r0 = 0, tau = 0, cc = 0, ss = 0, d_ = 0, phibar = 0;
+  int j = 1;
+  Control sc{c.outer};
+  history.clear();
+  int rc = system_apply(P, x, m0);
+  if (rc != ALFD_OK) return rc;
+  for (int64_t i = 0; i < N; ++i) u1[i] = b[i] - m0[i];
+  rc = precond_apply(P, u1, v.data());
+  if (rc != ALFD_OK) return rc;
+  delta[1] = pdot(P, v.data(), u1);
+  if (delta[1] < 0) return ALFD_E_BREAKDOWN;  // ExcPreconditionerNotDefinite
+  r0 = std::sqrt(delta[1]);
+  r_l2 = r0;
+  phibar = r0;
+  std::fill(U[0].begin(), U[0].end(), 0.0);
+  delta[0] = 1.0;
+  for (int i = 0; i < 3; ++i) std::fill(Mv[i].begin(), Mv[i].end(), 0.0);
+  State st = sc.check(0, r_l2);
+  history.push_back(r_l2);
+  if (c.log_level >= 2) std::printf("DEAL:minres::Check 0\t%.17g\n", r_l2);
+  while (st == ITERATE) {
+    if (delta[1] != 0)
+      scale(N, 1.0 / std::sqrt(delta[1]), v.data());
+    else
+      std::fill(v.begin(), v.end(), 0.0);
+    rc = system_apply(P, v.data(), u2);
+    if (rc != ALFD_OK) return rc;
+    axpy(N, -std::sqrt(delta[1] / delta[0]), u0, u2);
+    const double gamma = pdot(P, u2, v.data());
+    axpy(N, -gamma / std::sqrt(delta[1]), u1, u2);
+    std::memcpy(m0, v.data(), N * sizeof(double));
+    rc = precond_apply(P, u2, v.data());
+    if (rc != ALFD_OK) return rc;
+    delta[2] = pdot(P, v.data(), u2);
+    if (delta[2] < 0) return ALFD_E_BREAKDOWN;
+    if (j == 1) {
+      d_ = gamma;
+      e[1] = std::sqrt(delta[2]);
+    }
+    if (j > 1) {
+      d_ = ss * e[0] - cc * gamma;
+      e[0] = cc * e[0] + ss * gamma;
+      f[1] = ss * std::sqrt(delta[2]);
+      e[1] = -cc * std::sqrt(delta[2]);
+    }
+    const double d = std::sqrt(d_ * d_ + delta[2]);
+    // tau_j = c_j * phibar_{j-1}, phibar_j = s_j * phibar_{j-1}, phibar_0 = r0.  (The
+    // recurrence tau *= s/c; tau *= c of the textbook form divides by c_{j-1}, which is
+    // exactly 0 when the first Lanczos coefficient vanishes -- f = 0 in a saddle-point
+    // system with a block-diagonal preconditioner; this product form is identical
+    // otherwise.)
+    cc = d_ / d;
+    ss = std::sqrt(delta[2]) / d;
+    tau = cc * phibar;
+    phibar = ss * phibar;
+    axpy(N, -e[0], m1, m0);
+    if (j > 1) axpy(N, -f[0], m2, m0);
+    scale(N, 1.0 / d, m0);
+    axpy(N, tau, m0, x);
+    r_l2 *= std::fabs(ss);
+    st = sc.check(j, r_l2);
+    history.push_back(r_l2);
+    if (c.log_level >= 2) std::printf("DEAL:minres::Check %d\t%.17g\n", j, r_l2);
+    ++j;
+    double *t = u0;  // u0 <- u1 <- u2 <- (old u0)
+    u0 = u1;
+    u1 = u2;
+    u2 = t;
+    t = m2;          // m2 <- m1 <- m0 <- (old m2)
+    m2 = m1;
+    m1 = m0;
+    m0 = t;
+    delta[0] = delta[1];
+    delta[1] = delta[2];
+    f[0] = f[1];
+    e[0] = e[1];
+  }
+  out->outer_iterations = j - 1;
+  out->initial_residual = sc.initial;
+  out->last_residual = r_l2;
+  if (c.log_level >= 1)
+    std::printf(st == SUCCESS ? "DEAL:minres::Convergence step %d value %.17g\n"
+                              : "DEAL:minres::Failure step %d value %.17g\n",
+                j - 1, r_l2);
+  if (st != SUCCESS) return std::isnan(r_l2) ? ALFD_E_BREAKDOWN : ALFD_E_NO_CONVERGENCE_OUTER;
+  return ALFD_OK;
+}
+
 }  // namespace orc
 
 // ------------------------------------------------------------------- C API
@@ -785,9 +983,17 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
     m.val = op->mat[s].val;
   }
   for (int d = 0; d < ALFD_NDIAGS; ++d) P.diag[d] = op->diag[d];
-  if (!P.mat[ALFD_A].present() || !P.mat[ALFD_CT].present() || !P.diag[ALFD_INVW]) return ALFD_E_INVALID;
+  if (!P.mat[ALFD_A].present() || !P.mat[ALFD_CT].present()) return ALFD_E_INVALID;
+  if (!P.diag[ALFD_INVW] && cfg->variant != ALFD_RATIONAL) return ALFD_E_INVALID;
   if (!P.mat[ALFD_C].present()) orc::transpose_into(P.mat[ALFD_CT], P.mat[ALFD_C]);
   const bool ell = cfg->variant == ALFD_AL_ELL_IDEAL || cfg->variant == ALFD_AL_ELL_MODIFIED;
+  if (cfg->variant == ALFD_RATIONAL) {
+    const orc::Csr &K = P.mat[ALFD_KIMM], &M = P.mat[ALFD_M];
+    if (P.nblocks != 2 || !K.present() || !M.present() || K.nnz() != M.nnz() || !(cfg->rho_bound > 0))
+      return ALFD_E_INVALID;
+    for (int64_t k = 0; k < K.nnz(); ++k)
+      if (K.col[k] != M.col[k]) return ALFD_E_INVALID;  // matrix.add() needs one sparsity pattern
+  }
   if (ell) {
     if (P.nblocks != 3 || !P.mat[ALFD_A2].present() || !P.mat[ALFD_M].present() || P.n[1] != P.n[2])
       return ALFD_E_INVALID;
@@ -826,6 +1032,7 @@ static void fill_result(const orc::Problem &P, alfd_result *res, int status) {
   res->inner_failures = P.inner_failures;
   res->precond_applications = P.precond_applications;
   res->lambda_max = P.lambda_max;
+  res->rational_iterations = P.rational_its;
 }
 
 int orc_spmv(const orc_csr *m, int lanes, int vec, const double *x, double *y, int mode, double alpha) {
@@ -896,7 +1103,8 @@ int orc_solve(const orc_problem *op, const alfd_config *cfg, const double *const
   pack(P, x, xx);
   std::memset(res, 0, sizeof(*res));
   const auto t0 = std::chrono::steady_clock::now();
-  rc = orc::fgmres(P, bb.data(), xx.data(), res, hist);
+  rc = cfg->outer_solver == ALFD_OUTER_MINRES ? orc::minres(P, bb.data(), xx.data(), res, hist)
+                                             : orc::fgmres(P, bb.data(), xx.data(), res, hist);
   res->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   unpack(P, xx, x);
   fill_result(P, res, rc);

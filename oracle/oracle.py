@@ -160,6 +160,12 @@ class OracleSystem:
         return rc, x, res, hist[:min(cnt.value, history_cap)].copy()
 
 
+def rational_system_from_problem(pb) -> OracleSystem:
+    """The non-augmented system + immersed matrices of the rational branch."""
+    mats = {k: pb.mats[k] for k in ("A", "Ct", "C", "M", "K")}
+    return OracleSystem(mats, {}, pb.block_sizes)
+
+
 def system_from_problem(pb, nranks_emulated=1, part_offsets=None) -> OracleSystem:
     """Wrap a problems.SyntheticProblem: W^-1 = 1/M_ii^2, Mp lumped inverse."""
     mats = {k: pb.mats[k] for k in ("A", "Ct", "C") if k in pb.mats}

@@ -57,6 +57,20 @@ def case(name):
         cfg.gamma, cfg.gamma2 = 10.0, (10.0 if ideal else 1e-2)            # prm:48-49
         cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 100000, 1e-2, 1e-20)  # prm:59-66
         cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-10)   # prm:76-83
+    elif name == "rational_minres":
+        # immersed_laplace "rational" branch: MinRes + RationalPreconditioner (immersed_laplace.cc:585-631)
+        pb = problems.laplace2d_circle(32, 3)
+        cfg = _abi.default_config(_abi.RATIONAL)
+        cfg.rho_bound = pb.rho_bound()
+        cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 5000, 1e-13, 1e-12)   # K_inv: UMFPACK in the reference
+        cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)   # Schur solver control
+    elif name == "stokes_minres_diag":
+        # stokes...:1056-1064: MinRes + BlockPreconditionerAugmentedLagrangianDiagonal
+        pb = problems.stokes3d_sphere(6, 0)
+        cfg = _abi.default_config(_abi.AL_STOKES_DIAG)
+        cfg.outer_solver = _abi.OUTER_MINRES
+        cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 5000, 1e-12, 1e-10)   # MinRes wants a linear SPD preconditioner
+        cfg.mp_inner = _abi.Control(_abi.CTRL_REDUCTION, 500, 1e-13, 1e-11)
     else:
         raise KeyError(name)
     cfg.inner.max_steps = max(cfg.inner.max_steps, 1000)
@@ -64,4 +78,22 @@ def case(name):
 
 
 ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes2d_circle", "stokes3d_sphere",
-             "stokes3d_restart", "elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3"]
+             "stokes3d_restart", "elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3",
+             "rational_minres", "stokes_minres_diag"]
+
+
+def oracle_system(pb, cfg):
+    from oracle import oracle
+    if cfg.variant == _abi.RATIONAL:
+        return oracle.rational_system_from_problem(pb)
+    return oracle.system_from_problem(pb)
+
+
+def prepared_rhs(osys, pb, cfg):
+    """The right-hand side the reference hands to the Krylov solver: augmented for the
+    AL variants of immersed_laplace / stokes (stokes...:1012-1018), plain otherwise."""
+    rhs = rhs_of(pb)
+    if cfg.variant in (_abi.AL2, _abi.AL_STOKES, _abi.AL_STOKES_DIAG):
+        rc, rhs = osys.augment_rhs(cfg, rhs)
+        assert rc == 0
+    return rhs

@@ -22,10 +22,8 @@ def main():
     out = {}
     for name in cases.ALL_CASES:
         pb, cfg = cases.case(name)
-        osys = oracle.system_from_problem(pb)
-        rhs = cases.rhs_of(pb)
-        if "A2" not in pb.mats:        # the AL rhs augmentation (stokes...:1012-1018); elliptic has g = 0
-            rc, rhs = osys.augment_rhs(cfg, rhs)
+        osys = cases.oracle_system(pb, cfg)
+        rhs = cases.prepared_rhs(osys, pb, cfg)
         rc, x, res, hist = osys.solve(cfg, rhs)
         assert rc == 0, (name, rc)
         out[name] = {
@@ -33,6 +31,7 @@ def main():
             "outer_iterations": res.outer_iterations,
             "inner_iterations": res.inner_iterations,
             "mp_iterations": res.mp_iterations,
+            "rational_iterations": res.rational_iterations,
             "lambda_max": float(res.lambda_max).hex(),
             "history": [float(h).hex() for h in hist],
             "x_block_norms": [float((b * b).sum() ** 0.5).hex() for b in x],
