@@ -18,7 +18,7 @@ AL2, AL_STOKES, AL_STOKES_DIAG, AL_ELL_IDEAL, AL_ELL_MODIFIED, RATIONAL = range(
 # enum alfd_control_kind
 CTRL_ABS, CTRL_REDUCTION, CTRL_FIXED_ITERS = range(3)
 # enum alfd_inner_prec
-PREC_IDENTITY, PREC_JACOBI, PREC_CHEBYSHEV = range(3)
+PREC_IDENTITY, PREC_JACOBI, PREC_CHEBYSHEV, PREC_MULTILEVEL = range(4)
 # enum alfd_orthogonalization
 ORTH_MGS, ORTH_CGS, ORTH_CGS2 = range(3)
 # enum alfd_outer_solver
@@ -49,6 +49,8 @@ class Config(C.Structure):
         ("cheb_eig_ratio", C.c_double), ("cheb_safety", C.c_double),
         ("log_level", C.c_int32), ("outer_solver", C.c_int32),
         ("rho_bound", C.c_double), ("rational", Control),
+        ("ml_smooth_degree", C.c_int32), ("ml_coarse_degree", C.c_int32),
+        ("ml_smooth_ratio", C.c_double), ("ml_coarse_ratio", C.c_double),
     ]
 
 
@@ -88,4 +90,6 @@ def default_config(variant=AL_STOKES) -> Config:
     c.outer_solver = OUTER_MINRES if variant == RATIONAL else OUTER_FGMRES
     c.rho_bound = 0.0
     c.rational = Control(CTRL_ABS, 2000, 1e-14, 0.0)      # rational_preconditioner.h:34
+    c.ml_smooth_degree, c.ml_coarse_degree = 3, 40
+    c.ml_smooth_ratio, c.ml_coarse_ratio = 4.0, 400.0
     return c

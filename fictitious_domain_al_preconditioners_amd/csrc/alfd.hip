@@ -84,6 +84,26 @@ struct DevCsr {
   }
 };
 
+struct HostCsr {
+  int64_t nrows = 0, ncols = 0;
+  std::vector<int64_t> rp;
+  std::vector<int32_t> col;
+  std::vector<double> val;
+  int64_t nnz() const { return rp.empty() ? 0 : rp.back(); }
+};
+
+constexpr int kScratchSlot = ALFD_NSLOTS;  // internal upload target (level matrices, batched systems)
+
+// One level of the aggregation multigrid hierarchy (level 0 = the augmented block itself).
+struct MlLevel {
+  DevCsr A, C, Ct;   // operator pieces of this level (levels >= 1; level 0 uses the slots)
+  DevCsr P, R;       // prolongation to this level from the next coarser one, and R = P^T
+  int64_t n = 0, npad = 0;
+  double *dinv = nullptr;
+  double lmax = 0;
+  double *r = nullptr, *z = nullptr, *t = nullptr, *cd = nullptr, *cres = nullptr, *ctmp = nullptr;
+};
+
 enum State { ITERATE = 0, SUCCESS = 1, FAILURE = 2 };
 struct Control {
   alfd_control c;
@@ -127,7 +147,7 @@ struct alfd_ctx {
   int64_t n[ALFD_MAX_BLOCKS] = {0, 0, 0};        // local block lengths
   int64_t off[ALFD_MAX_BLOCKS + 1] = {0, 0, 0, 0};  // padded local offsets
   int64_t nmax = 0;                               // max padded block length
-  DevCsr mat[ALFD_NSLOTS];
+  DevCsr mat[ALFD_NSLOTS + 1];
   double *diag[ALFD_NDIAGS] = {nullptr, nullptr};
   int64_t diag_n[ALFD_NDIAGS] = {0, 0};
   alfd_config cfg;
@@ -143,12 +163,12 @@ struct alfd_ctx {
   double lam_max[6] = {0, 0, 0, 0, 0, 0};              // per inner operator kind
   double *dinv_k = nullptr;                            // rational: 1/diag(K)
   // RationalPreconditioner state (batched CG over the 21 immersed systems)
-  struct HostCsr {
-    int64_t nrows = 0, ncols = 0;
-    std::vector<int64_t> rp;
-    std::vector<int32_t> col;
-    std::vector<double> val;
-  } h_M, h_K;                                          // host copies of the (tiny) immersed matrices
+  HostCsr h_M, h_K;                                    // host copies of the (tiny) immersed matrices
+  // multilevel inner preconditioner
+  std::vector<int32_t> ml_agg[ALFD_MAX_LEVELS];
+  std::vector<double> ml_wgt[ALFD_MAX_LEVELS];
+  int64_t ml_ncoarse[ALFD_MAX_LEVELS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<MlLevel> ml;
   DevCsr rat_mat;                                      // block-diagonal [S_1 .. S_20, M]
   double *rt_r = nullptr, *rt_z = nullptr, *rt_p = nullptr, *rt_Ap = nullptr, *rt_x = nullptr;
   double *rt_dinv = nullptr, *rt_partial = nullptr, *rt_scb = nullptr, *rt_coef = nullptr;
@@ -397,10 +417,9 @@ static bool launch_window_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, do
 static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x);
 
 // epi 0: y = A x; 1: y = fma(alpha, A x, y); 2: y = d .* (A x); 3: y = A x, y2 = d .* y
-static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, double alpha = 0.0,
-                const double *d = nullptr, double *y2 = nullptr) {
-  DevCsr &m = ctx->mat[slot];
-  if (!m.present) return ctx->err = "matrix slot " + std::to_string(slot) + " not set", ALFD_E_NOT_SETUP;
+static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y, int epi, double alpha = 0.0,
+                  const double *d = nullptr, double *y2 = nullptr) {
+  if (!m.present) return ctx->err = "matrix not set", ALFD_E_NOT_SETUP;
   // RCCL send/recv pairs can be skipped by ranks with nothing to exchange; the
   // barrier-based in-process group needs every rank in every exchange.
   if (ctx->nranks > 1 && (ctx->local || m.n_halo > 0 || m.send_off.back() > 0)) RC(halo_exchange(ctx, m, x));
@@ -410,7 +429,7 @@ static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, do
     if (epi == 3) HIPC(hipMemsetAsync(y2, 0, m.nrows * sizeof(double), ctx->stream));
   }
   if (m.n_list == 0) return ALFD_OK;
-  Timer tm(ctx, slot == ALFD_A ? ALFD_T_SPMV_A : ALFD_T_SPMV_OTHER, m.algorithmic_bytes());
+  Timer tm(ctx, cls, m.algorithmic_bytes());
   if (m.win && launch_window_RU(ctx, m, x, y, epi, alpha, d, y2)) {
     HIPC(hipGetLastError());
     return ALFD_OK;
@@ -432,6 +451,13 @@ static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, do
   }
   HIPC(hipGetLastError());
   return ALFD_OK;
+}
+
+static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, double alpha = 0.0,
+                const double *d = nullptr, double *y2 = nullptr) {
+  DevCsr &m = ctx->mat[slot];
+  if (!m.present) return ctx->err = "matrix slot " + std::to_string(slot) + " not set", ALFD_E_NOT_SETUP;
+  return spmv_m(ctx, m, slot == ALFD_A ? ALFD_T_SPMV_A : ALFD_T_SPMV_OTHER, x, y, epi, alpha, d, y2);
 }
 
 // ------------------------------------------------------------ reductions
@@ -563,6 +589,7 @@ static int cheb_apply(alfd_ctx *ctx, int op, const double *r, double *z, int64_t
 
 // deal.II SolverCG via inverse_operator (zero initial guess) [EXT]; b and x are
 // padded device vectors of the operator's span.
+static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z);
 static int pcg(alfd_ctx *ctx, int op, int prec, const alfd_control &ctrl, const double *b, double *x,
                int *its_out, State *st_out, double *res_out) {
   const int64_t npad = op_npad(ctx, op);
@@ -589,6 +616,9 @@ static int pcg(alfd_ctx *ctx, int op, int prec, const alfd_control &ctrl, const 
     } else if (prec == ALFD_PREC_JACOBI) {
       VEC_LAUNCH(jacobi_dot_kernel, npad, 24, dinv, r, z, ctx->partial);
       RC(finish_dots(ctx, nb, 1, 0, FIN_RZ));
+    } else if (prec == ALFD_PREC_MULTILEVEL && op == OP_AUG) {
+      RC(ml_cycle(ctx, 0, r, z));
+      RC(dot_async(ctx, npad, r, z, 0, FIN_RZ));
     } else {
       RC(cheb_apply(ctx, op, r, z, npad));
       RC(dot_async(ctx, npad, r, z, 0, FIN_RZ));
@@ -1371,9 +1401,11 @@ static int ws_alloc_zero(alfd_ctx *ctx, double **p, int64_t count) {
 }
 
 // dinv = 1 / (diag(Adiag) + g * sum_k w_k R_ik^2): the diagonal of Adiag + g R diag(w) R^T
+static int diag_plus_m(alfd_ctx *ctx, const DevCsr &A, DevCsr &R, double g, int64_t n, double *dinv);
 static int diag_plus(alfd_ctx *ctx, int slot_diag, int slot_rows, double g, int64_t n, double *dinv) {
-  const DevCsr &A = ctx->mat[slot_diag];
-  DevCsr &R = ctx->mat[slot_rows];
+  return diag_plus_m(ctx, ctx->mat[slot_diag], ctx->mat[slot_rows], g, n, dinv);
+}
+static int diag_plus_m(alfd_ctx *ctx, const DevCsr &A, DevCsr &R, double g, int64_t n, double *dinv) {
   HIPC(hipMemsetAsync(ctx->dA, 0, pad_chunk(n) * sizeof(double), ctx->stream));
   HIPC(hipMemsetAsync(ctx->s_aug, 0, pad_chunk(n) * sizeof(double), ctx->stream));
   const int grid = grid_for_rows(A.nrows, A.L);
@@ -1438,6 +1470,277 @@ static int power_iteration(alfd_ctx *ctx, int op) {
   return ALFD_OK;
 }
 
+// ======================================================================
+// Aggregation multigrid for the augmented block (ALFD_PREC_MULTILEVEL).
+// Level l+1 = Galerkin coarsening of level l through the caller's aggregates:
+//   A_{l+1} = P^T A_l P,  C_{l+1} = C_l P,  Aug_{l+1} = A_{l+1} + gamma C_{l+1}^T invW C_{l+1}
+// (kept factored on every level, like the fine operator).  The cycle is a
+// symmetric V-cycle: Chebyshev pre-smoothing from zero, coarse correction,
+// Chebyshev post-smoothing of the residual; the coarsest level is "solved" by a
+// high-degree Chebyshev sweep.  Every piece is a fixed polynomial in SPD
+// operators, so the preconditioner is a fixed SPD operator and plain CG applies.
+static int download_csr(alfd_ctx *ctx, const DevCsr &m, HostCsr &h) {
+  h.nrows = m.nrows;
+  h.ncols = m.ncols;
+  h.col.resize(m.nnz);
+  h.val.resize(m.nnz);
+  HIPC(hipMemcpyAsync(h.col.data(), m.col, m.nnz * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipMemcpyAsync(h.val.data(), m.val, m.nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  h.rp.assign(m.nrows + 1, 0);
+  if (m.sparse) {
+    std::vector<int32_t> rows(m.n_list);
+    std::vector<int64_t> crp(m.n_list + 1);
+    HIPC(hipMemcpyAsync(rows.data(), m.rows, m.n_list * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(crp.data(), m.rp, (m.n_list + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < m.n_list; ++i) h.rp[rows[i] + 1] = crp[i + 1] - crp[i];
+    for (int64_t r = 0; r < m.nrows; ++r) h.rp[r + 1] += h.rp[r];
+  } else {
+    HIPC(hipMemcpyAsync(h.rp.data(), m.rp, (m.nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+  }
+  return ALFD_OK;
+}
+
+static void transpose_host(const HostCsr &a, HostCsr &t) {
+  t.nrows = a.ncols;
+  t.ncols = a.nrows;
+  const int64_t nnz = a.nnz();
+  t.rp.assign(t.nrows + 1, 0);
+  t.col.resize(nnz);
+  t.val.resize(nnz);
+  for (int64_t k = 0; k < nnz; ++k) t.rp[a.col[k] + 1]++;
+  for (int64_t r = 0; r < t.nrows; ++r) t.rp[r + 1] += t.rp[r];
+  std::vector<int64_t> cur(t.rp.begin(), t.rp.end() - 1);
+  for (int64_t r = 0; r < a.nrows; ++r)
+    for (int64_t k = a.rp[r]; k < a.rp[r + 1]; ++k) {
+      const int64_t p = cur[a.col[k]]++;
+      t.col[p] = (int32_t)r;
+      t.val[p] = a.val[k];
+    }
+}
+
+// out = R A Q for aggregation-type transfers.  Row I of out collects the fine rows i with
+// agg_row[i] == I (agg_row == nullptr: I == i); column J collects agg_col[j] == J.
+// Canonical accumulation order (the oracle follows it too): fine rows ascending, entries
+// in CSR order, each added to its coarse entry as it is met; the finished row is sorted
+// by column.
+static void galerkin(const HostCsr &A, const int32_t *agg_row, const double *w_row, int64_t n_rows_c,
+                     const int32_t *agg_col, const double *w_col, int64_t n_cols_c, HostCsr &out) {
+  std::vector<int64_t> mem_ptr;
+  std::vector<int32_t> mem;
+  if (agg_row) {
+    mem_ptr.assign(n_rows_c + 1, 0);
+    for (int64_t i = 0; i < A.nrows; ++i)
+      if (agg_row[i] >= 0) mem_ptr[agg_row[i] + 1]++;
+    for (int64_t I = 0; I < n_rows_c; ++I) mem_ptr[I + 1] += mem_ptr[I];
+    mem.resize(mem_ptr[n_rows_c]);
+    std::vector<int64_t> cur(mem_ptr.begin(), mem_ptr.end() - 1);
+    for (int64_t i = 0; i < A.nrows; ++i)
+      if (agg_row[i] >= 0) mem[cur[agg_row[i]]++] = (int32_t)i;
+  }
+  const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::vector<int64_t>> t_cnt(T);
+  std::vector<std::vector<int32_t>> t_col(T);
+  std::vector<std::vector<double>> t_val(T);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() {
+      const int64_t I0 = n_rows_c * t / T, I1 = n_rows_c * (t + 1) / T;
+      std::vector<int64_t> marker(n_cols_c, -1);
+      std::vector<std::pair<int32_t, double>> row;
+      for (int64_t I = I0; I < I1; ++I) {
+        row.clear();
+        const int64_t m0 = agg_row ? mem_ptr[I] : I, m1 = agg_row ? mem_ptr[I + 1] : I + 1;
+        for (int64_t mi = m0; mi < m1; ++mi) {
+          const int64_t i = agg_row ? mem[mi] : mi;
+          const double wi = w_row ? w_row[i] : 1.0;
+          for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+            const int32_t j = A.col[k];
+            const int32_t J = agg_col ? agg_col[j] : j;
+            if (J < 0) continue;
+            const double wj = w_col ? w_col[j] : 1.0;
+            const double c = (w_row || w_col) ? (wi * wj) * A.val[k] : A.val[k];
+            if (marker[J] < 0) {
+              marker[J] = (int64_t)row.size();
+              row.emplace_back(J, c);
+            } else {
+              row[marker[J]].second = row[marker[J]].second + c;
+            }
+          }
+        }
+        for (auto &e : row) marker[e.first] = -1;
+        std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        t_cnt[t].push_back((int64_t)row.size());
+        for (auto &e : row) {
+          t_col[t].push_back(e.first);
+          t_val[t].push_back(e.second);
+        }
+      }
+    });
+  for (auto &x : th) x.join();
+  out.nrows = n_rows_c;
+  out.ncols = n_cols_c;
+  out.rp.assign(1, 0);
+  out.col.clear();
+  out.val.clear();
+  for (int t = 0; t < T; ++t) {
+    for (int64_t c : t_cnt[t]) out.rp.push_back(out.rp.back() + c);
+    out.col.insert(out.col.end(), t_col[t].begin(), t_col[t].end());
+    out.val.insert(out.val.end(), t_val[t].begin(), t_val[t].end());
+  }
+}
+
+static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, const int64_t *rp,
+                         const int32_t *col, const double *val);
+static int upload_level(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h) {
+  static const int32_t no_col = 0;
+  static const double no_val = 0;
+  RC(upload_matrix(ctx, kScratchSlot, h.nrows, h.ncols, h.rp.data(), h.col.empty() ? &no_col : h.col.data(),
+                   h.val.empty() ? &no_val : h.val.data()));
+  dst = ctx->mat[kScratchSlot];
+  return ALFD_OK;
+}
+
+// y = Aug_l x
+static int level_op(alfd_ctx *ctx, int l, const double *x, double *y) {
+  if (l == 0) return op_apply(ctx, OP_AUG, x, y);
+  MlLevel &L = ctx->ml[l];
+  RC(spmv_m(ctx, L.A, ALFD_T_SPMV_OTHER, x, y, 0));
+  RC(spmv_m(ctx, L.C, ALFD_T_SPMV_OTHER, x, ctx->t_lam, 2, 0.0, ctx->diag[ALFD_INVW]));
+  return spmv_m(ctx, L.Ct, ALFD_T_SPMV_OTHER, ctx->t_lam, y, 1, ctx->cfg.gamma);
+}
+
+// z = p_k(D^-1 Aug_l) D^-1 r on level l (Chebyshev, zero start)
+static int level_cheb(alfd_ctx *ctx, int l, int degree, double ratio, const double *r, double *z) {
+  MlLevel &L = ctx->ml[l];
+  const double lmax = L.lmax, lmin = lmax / ratio;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  VEC_LAUNCH(cheb_init_kernel, L.npad, degree > 1 ? 40 : 32, 1.0 / theta, L.dinv, r, L.cd, z, L.cres,
+             degree > 1 ? 1 : 0);
+  for (int j = 1; j < degree; ++j) {
+    RC(level_op(ctx, l, L.cd, L.ctmp));
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    VEC_LAUNCH(cheb_step_kernel, L.npad, 64, c1, c2, L.dinv, L.ctmp, L.cres, L.cd, z);
+    rho = rho_new;
+  }
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+// z = V-cycle(r) on level l
+static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z) {
+  const alfd_config &c = ctx->cfg;
+  const int last = (int)ctx->ml.size() - 1;
+  if (l == last) return level_cheb(ctx, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  MlLevel &L = ctx->ml[l], &N = ctx->ml[l + 1];
+  RC(level_cheb(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, r, z));       // pre-smoothing from zero
+  RC(level_op(ctx, l, z, L.t));
+  VEC_LAUNCH(sub_from_kernel, L.npad, 24, r, L.t);                           // t = r - Aug z
+  RC(spmv_m(ctx, N.R, ALFD_T_SPMV_OTHER, L.t, N.r, 0));                      // r_c = P^T t
+  RC(ml_cycle(ctx, l + 1, N.r, N.z));
+  RC(spmv_m(ctx, N.P, ALFD_T_SPMV_OTHER, N.z, z, 1, 1.0));                   // z += P e_c
+  RC(level_op(ctx, l, z, L.t));
+  VEC_LAUNCH(sub_from_kernel, L.npad, 24, r, L.t);
+  RC(level_cheb(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, L.t, L.r));   // post-smoothing correction
+  VEC_LAUNCH(axpy_kernel, L.npad, 24, (const double *)nullptr, 0, 1.0, L.r, z);
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+static int ws_alloc_zero(alfd_ctx *ctx, double **p, int64_t count);
+
+static int ml_setup(alfd_ctx *ctx) {
+  const alfd_config &c = ctx->cfg;
+  if (ctx->nranks > 1) return ctx->err = "multilevel inner preconditioner is single-rank for now", ALFD_E_UNSUPPORTED;
+  if (c.ml_smooth_degree < 1 || c.ml_coarse_degree < 1 || !(c.ml_smooth_ratio > 1.0) || !(c.ml_coarse_ratio > 1.0))
+    return ctx->err = "bad multilevel parameters", ALFD_E_INVALID;
+  int nlev = 0;
+  while (nlev < ALFD_MAX_LEVELS && !ctx->ml_agg[nlev].empty()) ++nlev;
+  if (nlev == 0) return ctx->err = "alfd_set_aggregates must precede alfd_setup for ALFD_PREC_MULTILEVEL", ALFD_E_NOT_SETUP;
+  if ((int64_t)ctx->ml_agg[0].size() != ctx->n[0]) return ctx->err = "aggregates of level 0 do not match block 0", ALFD_E_INVALID;
+  for (int l = 1; l < nlev; ++l)
+    if ((int64_t)ctx->ml_agg[l].size() != ctx->ml_ncoarse[l - 1])
+      return ctx->err = "aggregates of level " + std::to_string(l) + " do not match the previous level", ALFD_E_INVALID;
+  ctx->ml.assign(nlev + 1, MlLevel());
+  HostCsr A, C, An, Cn, Ctn, P, R;
+  RC(download_csr(ctx, ctx->mat[ALFD_A], A));
+  RC(download_csr(ctx, ctx->mat[ALFD_C], C));
+  int64_t n = ctx->n[0];
+  for (int l = 0; l <= nlev; ++l) {
+    MlLevel &L = ctx->ml[l];
+    L.n = n;
+    L.npad = pad_chunk(n);
+    RC(ws_alloc_zero(ctx, &L.r, L.npad));
+    RC(ws_alloc_zero(ctx, &L.z, L.npad));
+    RC(ws_alloc_zero(ctx, &L.t, L.npad));
+    RC(ws_alloc_zero(ctx, &L.cd, L.npad));
+    RC(ws_alloc_zero(ctx, &L.cres, L.npad));
+    RC(ws_alloc_zero(ctx, &L.ctmp, L.npad));
+    if (l == 0) {
+      L.dinv = ctx->dinv_aug;
+      L.lmax = ctx->lam_max[OP_AUG];
+    } else {
+      RC(ws_alloc_zero(ctx, &L.dinv, L.npad));
+      RC(diag_plus_m(ctx, L.A, L.Ct, c.gamma, n, L.dinv));
+      // lambda_max(D^-1 Aug_l): power iteration from the integer-hash vector
+      double *v = L.t, *wv = L.r;
+      hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                         (int64_t)0, v);
+      double lam = 0;
+      for (int it = 0; it < c.cheb_power_its; ++it) {
+        RC(dot_async(ctx, L.npad, v, v, S_TMP));
+        RC(read_scalars(ctx, S_TMP, 1));
+        VEC_LAUNCH(scale_kernel, L.npad, 16, (const double *)nullptr, 0, 0,
+                   1.0 / std::sqrt(ctx->sc_host[S_TMP]), v);
+        RC(level_op(ctx, l, v, wv));
+        VEC_LAUNCH(pmul_scale_kernel, L.npad, 24, 1.0, L.dinv, wv, wv);
+        RC(dot_async(ctx, L.npad, wv, wv, S_TMP));
+        RC(read_scalars(ctx, S_TMP, 1));
+        lam = std::sqrt(ctx->sc_host[S_TMP]);
+        std::swap(v, wv);
+      }
+      L.lmax = lam * c.cheb_safety;
+      HIPC(hipMemsetAsync(L.t, 0, L.npad * sizeof(double), ctx->stream));
+      HIPC(hipMemsetAsync(L.r, 0, L.npad * sizeof(double), ctx->stream));
+    }
+    if (l == nlev) break;
+    // next level
+    const int32_t *agg = ctx->ml_agg[l].data();
+    const double *w = ctx->ml_wgt[l].empty() ? nullptr : ctx->ml_wgt[l].data();
+    const int64_t nc = ctx->ml_ncoarse[l];
+    galerkin(A, agg, w, nc, agg, w, nc, An);
+    galerkin(C, nullptr, nullptr, C.nrows, agg, w, nc, Cn);
+    transpose_host(Cn, Ctn);
+    P.nrows = n;
+    P.ncols = nc;
+    P.rp.assign(n + 1, 0);
+    P.col.clear();
+    P.val.clear();
+    for (int64_t i = 0; i < n; ++i) {
+      if (agg[i] >= 0) {
+        P.col.push_back(agg[i]);
+        P.val.push_back(w ? w[i] : 1.0);
+      }
+      P.rp[i + 1] = (int64_t)P.col.size();
+    }
+    transpose_host(P, R);
+    MlLevel &Nx = ctx->ml[l + 1];
+    RC(upload_level(ctx, Nx.A, An));
+    RC(upload_level(ctx, Nx.C, Cn));
+    RC(upload_level(ctx, Nx.Ct, Ctn));
+    RC(upload_level(ctx, Nx.P, P));
+    RC(upload_level(ctx, Nx.R, R));
+    A = std::move(An);
+    C = std::move(Cn);
+    n = nc;
+  }
+  return ALFD_OK;
+}
+
 static int setup(alfd_ctx *ctx) {
   if (!ctx->configured) return ctx->err = "alfd_configure not called", ALFD_E_NOT_SETUP;
   const alfd_config &c = ctx->cfg;
@@ -1449,7 +1752,7 @@ static int setup(alfd_ctx *ctx) {
   const bool ell = is_elliptic(c.variant);
   if (!c.grad_div_in_A && (c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG))
     return ctx->err = "grad_div_in_A = 0 (nested Bt Mp^-1 B in Aug) not implemented", ALFD_E_UNSUPPORTED;
-  if (c.inner_prec == ALFD_PREC_CHEBYSHEV &&
+  if ((c.inner_prec == ALFD_PREC_CHEBYSHEV || c.inner_prec == ALFD_PREC_MULTILEVEL) &&
       (c.cheb_degree < 1 || c.cheb_power_its < 1 || !(c.cheb_eig_ratio > 1.0)))
     return ctx->err = "bad Chebyshev parameters", ALFD_E_INVALID;
   // parameter sanity the reference asserts (elliptic_interface.cc:874-884, 912-920)
@@ -1467,7 +1770,7 @@ static int setup(alfd_ctx *ctx) {
   ctx->n[0] = ctx->mat[ALFD_A].nrows;
   ctx->n[last] = ctx->mat[ALFD_C].nrows;
   if (rat) {
-    const alfd_ctx::HostCsr &K = ctx->h_K, &M = ctx->h_M;
+    const HostCsr &K = ctx->h_K, &M = ctx->h_M;
     if (K.rp.empty() || M.rp.empty()) return ctx->err = "KIMM and M must be set for the rational variant", ALFD_E_NOT_SETUP;
     if (K.nrows != ctx->n[1] || M.nrows != ctx->n[1] || K.col != M.col || K.rp != M.rp)
       return ctx->err = "KIMM and M must share one sparsity pattern (matrix.add)", ALFD_E_INVALID;
@@ -1524,7 +1827,7 @@ static int setup(alfd_ctx *ctx) {
   RC(ws_alloc_zero(ctx, &ctx->bb, N));
   RC(ws_alloc_zero(ctx, &ctx->io, N));
   for (int k = 0; k < 6; ++k) ctx->lam_max[k] = 0;
-  const bool cheb = c.inner_prec == ALFD_PREC_CHEBYSHEV;
+  const bool cheb = c.inner_prec == ALFD_PREC_CHEBYSHEV || c.inner_prec == ALFD_PREC_MULTILEVEL;
   if (rat) {
     // K_inv: Jacobi / Chebyshev-Jacobi CG on K itself
     RC(ws_alloc_zero(ctx, &ctx->dinv_k, n0p));
@@ -1547,7 +1850,7 @@ static int setup(alfd_ctx *ctx) {
     }
     if (cheb) RC(power_iteration(ctx, OP_K));
     // block-diagonal matrix of the 21 immersed systems, segment s at rows/cols s*npl
-    const alfd_ctx::HostCsr &K = ctx->h_K, &M = ctx->h_M;
+    const HostCsr &K = ctx->h_K, &M = ctx->h_M;
     const int64_t n1 = ctx->n[1], npl = pad_chunk(n1), nnz1 = K.rp[n1];
     std::vector<int64_t> rp((size_t)npl * kRatSystems + 1, 0);
     std::vector<int32_t> col((size_t)nnz1 * kRatSystems);
@@ -1565,10 +1868,9 @@ static int setup(alfd_ctx *ctx) {
     }
     {
       // upload through the generic path into a scratch slot object
-      DevCsr keep = ctx->mat[ALFD_KIMM];
-      RC(upload_matrix(ctx, ALFD_KIMM, npl * kRatSystems, npl * kRatSystems, rp.data(), col.data(), val.data()));
-      ctx->rat_mat = ctx->mat[ALFD_KIMM];
-      ctx->mat[ALFD_KIMM] = keep;
+      RC(upload_matrix(ctx, kScratchSlot, npl * kRatSystems, npl * kRatSystems, rp.data(), col.data(),
+                       val.data()));
+      ctx->rat_mat = ctx->mat[kScratchSlot];
     }
     const int64_t nt = npl * kRatSystems;
     RC(ws_alloc_zero(ctx, &ctx->rt_r, nt));
@@ -1629,6 +1931,12 @@ static int setup(alfd_ctx *ctx) {
     RC(power_iteration(ctx, OP_AUG));
   }
   ctx->lambda_max = ctx->lam_max[c.variant == ALFD_AL_ELL_IDEAL ? OP_AUG2 : OP_AUG];
+  ctx->ml.clear();
+  if (c.inner_prec == ALFD_PREC_MULTILEVEL) {
+    if (c.variant == ALFD_AL_ELL_IDEAL)
+      return ctx->err = "multilevel inner preconditioner: not for the 2x2 block CG of the ideal variant", ALFD_E_UNSUPPORTED;
+    RC(ml_setup(ctx));
+  }
   HIPC(hipStreamSynchronize(ctx->stream));
   ctx->is_setup = true;
   return ALFD_OK;
@@ -1817,7 +2125,7 @@ int alfd_set_matrix(alfd_ctx_t ctx, int slot, int64_t nrows, int64_t ncols, cons
   RC(upload_matrix(ctx, slot, nrows, ncols, row_ptr, col, val));
   if ((slot == ALFD_M || slot == ALFD_KIMM) && nnz <= (int64_t)1 << 26) {
     // the rational preconditioner builds its 21 shifted systems from these on the host
-    alfd_ctx::HostCsr &h = slot == ALFD_M ? ctx->h_M : ctx->h_K;
+    HostCsr &h = slot == ALFD_M ? ctx->h_M : ctx->h_K;
     h.nrows = nrows;
     h.ncols = ncols;
     h.rp.assign(row_ptr, row_ptr + nrows + 1);
@@ -1868,6 +2176,27 @@ void alfd_default_config(alfd_config *c, int variant) {
   c->outer_solver = variant == ALFD_RATIONAL ? ALFD_OUTER_MINRES : ALFD_OUTER_FGMRES;
   c->rho_bound = 0.0;
   c->rational = {ALFD_CTRL_ABS, 2000, 1e-14, 0.0};
+  c->ml_smooth_degree = 3;
+  c->ml_coarse_degree = 40;
+  c->ml_smooth_ratio = 4.0;
+  c->ml_coarse_ratio = 400.0;
+}
+
+int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t *agg, const double *weight,
+                        int64_t n_coarse) {
+  CHECK_CTX();
+  if (level < 0 || level >= ALFD_MAX_LEVELS || n_fine < 1 || n_coarse < 1 || !agg) return ALFD_E_INVALID;
+  for (int64_t i = 0; i < n_fine; ++i)
+    if (agg[i] < -1 || agg[i] >= n_coarse) return ctx->err = "aggregate id out of range", ALFD_E_INVALID;
+  ctx->ml_agg[level].assign(agg, agg + n_fine);
+  if (weight)
+    ctx->ml_wgt[level].assign(weight, weight + n_fine);
+  else
+    ctx->ml_wgt[level].clear();
+  ctx->ml_ncoarse[level] = n_coarse;
+  for (int l = level + 1; l < ALFD_MAX_LEVELS; ++l) ctx->ml_agg[l].clear(), ctx->ml_wgt[l].clear();
+  ctx->is_setup = false;
+  return ALFD_OK;
 }
 
 int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg) {

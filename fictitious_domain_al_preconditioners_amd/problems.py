@@ -283,3 +283,48 @@ def elliptic_interface2d(n_bg=64, n_fg=16, beta1=1.0, beta2=10.0, coupling_nq=3)
     return generate(dim=2, degree=1, ncomp=1, n_cells=n_bg, lo=-1.0, hi=1.0, beta=beta1,
                     coupling_nq=coupling_nq, body_force=(1.0,), embedded_value=(0.0,),
                     immersed_box=(-0.14, 0.47, n_fg), beta2=beta2 - beta1)
+
+
+def geometric_aggregates(pb: SyntheticProblem, a: int = 2, min_coarse: int = 600, max_levels: int = 7):
+    """Aggregates for the multilevel inner preconditioner on the tensor-grid background
+    space: nodes are grouped in a^dim boxes (then boxes of boxes, ...), all components of
+    a node stay together (one coarse dof per box and component -- the constant modes ML is
+    given in utilities.h:304-311), Dirichlet nodes are left out (-1).  Returns
+    [(agg_level0, n_coarse0), (agg_level1, n_coarse1), ...] for Context.set_aggregates."""
+    if pb.row_ranges is not None:
+        raise ValueError("geometric_aggregates needs the unpartitioned problem")
+    P = pb.params
+    dim, ncomp = P["dim"], P["ncomp"]
+    n1 = P["degree"] * P["n_cells"] + 1
+    idx = np.arange(n1 ** dim, dtype=np.int64)
+    coords = np.stack([(idx // n1 ** d) % n1 for d in range(dim)], axis=1)     # [node, axis]
+    interior = np.all((coords > 0) & (coords < n1 - 1), axis=1)
+    levels = []
+    # level 0: interior nodes only
+    cur = coords[interior]
+    owner = -np.ones(idx.size, np.int64)          # fine node -> index into `cur`
+    owner[interior] = np.arange(cur.shape[0])
+    first = True
+    while len(levels) < max_levels:
+        box = cur // a
+        span = int(box.max()) + 1
+        key = np.zeros(box.shape[0], np.int64)
+        for d in reversed(range(dim)):
+            key = key * span + box[:, d]
+        uniq, inv = np.unique(key, return_inverse=True)       # coarse nodes, lexicographic in box index
+        if first:
+            node_agg = np.where(owner >= 0, inv[np.maximum(owner, 0)], -1)
+        else:
+            node_agg = inv
+        agg = node_agg[:, None] * ncomp + np.arange(ncomp)[None, :]
+        agg = np.where(node_agg[:, None] < 0, -1, agg).astype(np.int32).ravel()
+        n_coarse = int(uniq.size * ncomp)
+        levels.append((agg, n_coarse))
+        if n_coarse <= min_coarse or uniq.size == cur.shape[0]:
+            break
+        # coordinates of the coarse nodes = box indices
+        nxt = np.zeros((uniq.size, dim), np.int64)
+        nxt[inv] = box
+        cur = nxt
+        first = False
+    return levels

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "alfd_augment_rhs", "alfd_solve", "alfd_upload_rhs", "alfd_solve_resident", "alfd_download_solution",
     "alfd_get_history", "alfd_spmv", "alfd_dot", "alfd_matrix_lanes", "alfd_bench_spmv",
     "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan", "alfd_local_group_create",
-    "alfd_local_group_destroy", "alfd_comm_init_local",
+    "alfd_local_group_destroy", "alfd_comm_init_local", "alfd_set_aggregates",
 ]
 
 
@@ -87,6 +87,7 @@ def load_library():
         "alfd_local_group_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "alfd_local_group_destroy": (C.c_int, [vp]),
         "alfd_comm_init_local": (C.c_int, [vp, vp, C.c_int]),
+        "alfd_set_aggregates": (C.c_int, [vp, C.c_int, i64, vp, vp, i64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -160,6 +161,12 @@ class Context:
     def set_diag(self, slot, d):
         d = np.ascontiguousarray(d, np.float64)
         self._ck(self._lib.alfd_set_diag(self._h, slot, d.size, d.ctypes.data))
+
+    def set_aggregates(self, level, agg, n_coarse, weight=None):
+        agg = np.ascontiguousarray(agg, np.int32)
+        w = None if weight is None else np.ascontiguousarray(weight, np.float64)
+        self._ck(self._lib.alfd_set_aggregates(self._h, level, agg.size, agg.ctypes.data,
+                                               None if w is None else w.ctypes.data, int(n_coarse)))
 
     def configure(self, cfg: _abi.Config):
         self.cfg = cfg
@@ -297,10 +304,13 @@ def host_halo_plan(col, col_offsets, rank):
     return col_local, halo[:n_halo.value].copy(), recv_off
 
 
-def upload_problem(ctx: Context, pb, cfg: _abi.Config) -> Context:
+def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None) -> Context:
     """Upload a problems.SyntheticProblem (whole, or this rank's rows) with the
     reference's diagonal choices: W^-1 = 1/M_ii^2 (stokes...:976-978), lumped
-    pressure mass (stokes...:946-954)."""
+    pressure mass (stokes...:946-954).  aggregates: [(agg, n_coarse), ...] for
+    ALFD_PREC_MULTILEVEL (problems.geometric_aggregates)."""
+    for level, (agg, nc) in enumerate(aggregates or []):
+        ctx.set_aggregates(level, agg, nc)
     ctx.set_matrix(_abi.A, pb.mats["A"])
     ctx.set_matrix(_abi.CT, pb.mats["Ct"])
     ctx.set_matrix(_abi.C_, pb.mats["C"])
@@ -330,8 +340,8 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config) -> Context:
     return ctx
 
 
-def context_from_problem(pb, cfg: _abi.Config, device_id=0) -> Context:
-    return upload_problem(Context(device_id), pb, cfg)
+def context_from_problem(pb, cfg: _abi.Config, device_id=0, aggregates=None) -> Context:
+    return upload_problem(Context(device_id), pb, cfg, aggregates)
 
 
 # ---------------------------------------------------------------------------

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 2
+#define ALFD_ABI_VERSION 3
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -108,7 +108,16 @@ typedef struct alfd_control {
 /* Preconditioner of the inner CG on the augmented block.  The reference uses
  * Trilinos ML (stokes...:1027-1045); north_star replaces it by a Jacobi /
  * Chebyshev sweep. */
-enum alfd_inner_prec { ALFD_PREC_IDENTITY = 0, ALFD_PREC_JACOBI = 1, ALFD_PREC_CHEBYSHEV = 2 };
+enum alfd_inner_prec {
+  ALFD_PREC_IDENTITY = 0,
+  ALFD_PREC_JACOBI = 1,
+  ALFD_PREC_CHEBYSHEV = 2,
+  /* Aggregation multigrid V-cycle with Chebyshev smoothing on every level (the
+   * GPU counterpart of the ML smoothed-aggregation AMG the reference initialises
+   * in utilities.h:304-317).  Needs alfd_set_aggregates(); applies to the
+   * augmented (1,1) block, other inner operators fall back to CHEBYSHEV. */
+  ALFD_PREC_MULTILEVEL = 3
+};
 
 /* Arnoldi orthogonalisation in FGMRES [EXT]: deal.II <= 9.5 modified
  * Gram-Schmidt; >= 9.6 classical Gram-Schmidt variants. */
@@ -146,6 +155,11 @@ typedef struct alfd_config {
   /* ALFD_RATIONAL only (rational_preconditioner.h): */
   double rho_bound;           /* ||A_Gamma||_inf / min_i M_ii, immersed_laplace.cc:609-614 */
   alfd_control rational;      /* SolverControl(2000, 1e-14) of the 21 immersed solves, :34 */
+  /* ALFD_PREC_MULTILEVEL only (ML: smoother_sweeps = 2, utilities.h:312): */
+  int32_t ml_smooth_degree;   /* Chebyshev degree of the pre-/post-smoother on every level */
+  int32_t ml_coarse_degree;   /* Chebyshev degree that stands in for the coarsest-level solve */
+  double ml_smooth_ratio;     /* smoother targets [lambda_max/ratio, lambda_max] */
+  double ml_coarse_ratio;     /* same for the coarsest level */
 } alfd_config;
 
 typedef struct alfd_result {
@@ -217,6 +231,16 @@ int alfd_set_matrix(alfd_ctx_t ctx, int slot, int64_t nrows, int64_t ncols, cons
                     const int32_t *col, const double *val);
 /* Replaces: DiagonalMatrix<Vector<double>> (stokes...:954, 980). n = local length. */
 int alfd_set_diag(alfd_ctx_t ctx, int slot, int64_t n, const double *d);
+#define ALFD_MAX_LEVELS 8
+/* Aggregates of the multilevel inner preconditioner (replaces ML's aggregation,
+ * utilities.h:304-317): level l maps the n_fine unknowns of level l (level 0 = block 0,
+ * the velocity / background space) onto n_coarse unknowns of level l+1.  agg[i] in
+ * [0, n_coarse) or -1 (not represented on the coarse level, e.g. Dirichlet rows);
+ * weight[i] (NULL = 1) is the prolongation entry P_{i,agg[i]} -- pass the near-nullspace
+ * vector for non-constant modes.  Coarse operators are the Galerkin products
+ * P^T (A + gamma Ct invW C) P, kept factored as (P^T A P) + gamma (C P)^T invW (C P). */
+int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t *agg, const double *weight,
+                        int64_t n_coarse);
 int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg);
 void alfd_default_config(alfd_config *cfg, int variant);
 /* Builds transposes, sparse-row views, diag(Aug), lambda_max, halo plans

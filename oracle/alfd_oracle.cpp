@@ -38,6 +38,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -223,6 +224,18 @@ struct Problem {
   std::vector<double> dinv_aug, dinv_a22, dinv_aug2, dinv_k;  // 1/diag of the inner operators
   double lam_max[6] = {0, 0, 0, 0, 0, 0};             // per inner operator kind
   std::vector<Csr> shifted;                           // A_Gamma - rho p_i M (rational_preconditioner.h:42-45)
+  // aggregation multigrid (ALFD_PREC_MULTILEVEL): inputs + hierarchy
+  int ml_nlev = 0;
+  const int32_t *ml_agg[ALFD_MAX_LEVELS] = {};
+  const double *ml_wgt[ALFD_MAX_LEVELS] = {};
+  int64_t ml_nc[ALFD_MAX_LEVELS] = {};
+  struct Level {
+    Csr A, C, Ct, Pm, R;
+    int64_t n = 0;
+    std::vector<double> dinv;
+    double lmax = 0;
+  };
+  std::vector<Level> ml;
   std::vector<std::vector<double>> shifted_dinv;
   int64_t rational_its = 0;
   double lambda_max = 0;
@@ -434,6 +447,13 @@ static const double *op_dinv(const Problem &P, int kind) {
          : kind == OP_K ? P.dinv_k.data() : P.dinv_aug2.data();
 }
 
+static void ml_setup(Problem &P);
+static void ml_cycle(Problem &P, int l, const double *r, double *z);
+struct MlPrec {
+  Problem &P;
+  void operator()(const double *r, double *z, int64_t) { ml_cycle(P, 0, r, z); }
+};
+
 static int inner_solve(Problem &P, int kind, const double *b, double *x) {
   InnerOp op{P, kind, {}};
   int its = 0;
@@ -449,6 +469,9 @@ static int inner_solve(Problem &P, int kind, const double *b, double *x) {
       st = pcg(P, op, pr, P.cfg.inner, b, x, its, res, P.cfg.log_level, "aug");
     } else if (P.cfg.inner_prec == ALFD_PREC_JACOBI) {
       DiagPrec pr{op_dinv(P, kind)};
+      st = pcg(P, op, pr, P.cfg.inner, b, x, its, res, P.cfg.log_level, "aug");
+    } else if (P.cfg.inner_prec == ALFD_PREC_MULTILEVEL && kind == OP_AUG) {
+      MlPrec pr{P};
       st = pcg(P, op, pr, P.cfg.inner, b, x, its, res, P.cfg.log_level, "aug");
     } else {
       InnerOp op2{P, kind, {}};
@@ -515,7 +538,7 @@ static void power_iteration(Problem &P, int kind) {
 static void setup(Problem &P) {
   const double *w = P.diag[ALFD_INVW];
   for (int k = 0; k < 6; ++k) P.lam_max[k] = 0.0;
-  const bool cheb = P.cfg.inner_prec == ALFD_PREC_CHEBYSHEV;
+  const bool cheb = P.cfg.inner_prec == ALFD_PREC_CHEBYSHEV || P.cfg.inner_prec == ALFD_PREC_MULTILEVEL;
   if (P.cfg.variant == ALFD_RATIONAL) {
     const Csr &A = P.mat[ALFD_A];
     P.dinv_k.assign(P.n[0], 1.0);
@@ -545,6 +568,165 @@ static void setup(Problem &P) {
     power_iteration(P, OP_AUG);
   }
   P.lambda_max = P.lam_max[is_elliptic(P.cfg.variant) && P.cfg.variant == ALFD_AL_ELL_IDEAL ? OP_AUG2 : OP_AUG];
+  if (P.cfg.inner_prec == ALFD_PREC_MULTILEVEL && P.ml_nlev > 0) ml_setup(P);
+}
+
+// ---- aggregation multigrid for the augmented block -------------------------------
+// out = R A Q for aggregation-type transfers; canonical accumulation order: fine rows
+// ascending, entries in CSR order, each added to its coarse entry as met; row sorted by column.
+static void galerkin(const Csr &A, const int32_t *agg_row, const double *w_row, int64_t n_rows_c,
+                     const int32_t *agg_col, const double *w_col, int64_t n_cols_c, Csr &out) {
+  std::vector<std::vector<int32_t>> members;
+  if (agg_row) {
+    members.resize(n_rows_c);
+    for (int64_t i = 0; i < A.nrows; ++i)
+      if (agg_row[i] >= 0) members[agg_row[i]].push_back((int32_t)i);
+  }
+  out.nrows = n_rows_c;
+  out.ncols = n_cols_c;
+  out.own_rp.assign(1, 0);
+  out.own_col.clear();
+  out.own_val.clear();
+  std::vector<int64_t> marker(n_cols_c, -1);
+  std::vector<std::pair<int32_t, double>> row;
+  for (int64_t I = 0; I < n_rows_c; ++I) {
+    row.clear();
+    const int64_t cnt = agg_row ? (int64_t)members[I].size() : 1;
+    for (int64_t mi = 0; mi < cnt; ++mi) {
+      const int64_t i = agg_row ? members[I][mi] : I;
+      const double wi = w_row ? w_row[i] : 1.0;
+      for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+        const int32_t j = A.col[k];
+        const int32_t J = agg_col ? agg_col[j] : j;
+        if (J < 0) continue;
+        const double wj = w_col ? w_col[j] : 1.0;
+        const double c = (w_row || w_col) ? (wi * wj) * A.val[k] : A.val[k];
+        if (marker[J] < 0) {
+          marker[J] = (int64_t)row.size();
+          row.emplace_back(J, c);
+        } else {
+          row[marker[J]].second = row[marker[J]].second + c;
+        }
+      }
+    }
+    for (auto &e : row) marker[e.first] = -1;
+    std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (auto &e : row) {
+      out.own_col.push_back(e.first);
+      out.own_val.push_back(e.second);
+    }
+    out.own_rp.push_back((int64_t)out.own_col.size());
+  }
+  out.rp = out.own_rp.data();
+  out.col = out.own_col.data();
+  out.val = out.own_val.data();
+}
+
+static void level_op(Problem &P, int l, const double *x, double *y, std::vector<double> &t) {
+  const Csr &A = l == 0 ? P.mat[ALFD_A] : P.ml[l].A;
+  const Csr &C = l == 0 ? P.mat[ALFD_C] : P.ml[l].C;
+  const Csr &Ct = l == 0 ? P.mat[ALFD_CT] : P.ml[l].Ct;
+  spmv(A, x, y, 0, 0.0);
+  t.resize(C.nrows);
+  spmv(C, x, t.data(), 0, 0.0);
+  pmul(C.nrows, P.diag[ALFD_INVW], t.data(), t.data());
+  spmv(Ct, t.data(), y, 1, P.cfg.gamma);
+}
+
+static void level_cheb(Problem &P, int l, int degree, double ratio, const double *r, double *z) {
+  const Problem::Level &L = P.ml[l];
+  const int64_t n = L.n;
+  const double *dinv = l == 0 ? P.dinv_aug.data() : L.dinv.data();
+  const double lmax = L.lmax, lmin = lmax / ratio;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  std::vector<double> d(n), res, tmp(n), t;
+  const double inv_theta = 1.0 / theta;
+  for (int64_t i = 0; i < n; ++i) {
+    d[i] = inv_theta * (dinv[i] * r[i]);
+    z[i] = d[i];
+  }
+  if (degree > 1) res.assign(r, r + n);
+  for (int j = 1; j < degree; ++j) {
+    level_op(P, l, d.data(), tmp.data(), t);
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    for (int64_t i = 0; i < n; ++i) {
+      res[i] = res[i] - tmp[i];
+      d[i] = std::fma(c1, d[i], c2 * (dinv[i] * res[i]));
+      z[i] = z[i] + d[i];
+    }
+    rho = rho_new;
+  }
+}
+
+static void ml_cycle(Problem &P, int l, const double *r, double *z) {
+  const alfd_config &c = P.cfg;
+  const int last = (int)P.ml.size() - 1;
+  if (l == last) return level_cheb(P, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  const int64_t n = P.ml[l].n, nc = P.ml[l + 1].n;
+  std::vector<double> t(n), rc(nc), ec(nc), e(n), tl;
+  level_cheb(P, l, c.ml_smooth_degree, c.ml_smooth_ratio, r, z);
+  level_op(P, l, z, t.data(), tl);
+  sub_from(n, r, t.data());
+  spmv(P.ml[l + 1].R, t.data(), rc.data(), 0, 0.0);
+  ml_cycle(P, l + 1, rc.data(), ec.data());
+  spmv(P.ml[l + 1].Pm, ec.data(), z, 1, 1.0);
+  level_op(P, l, z, t.data(), tl);
+  sub_from(n, r, t.data());
+  level_cheb(P, l, c.ml_smooth_degree, c.ml_smooth_ratio, t.data(), e.data());
+  for (int64_t i = 0; i < n; ++i) z[i] = std::fma(1.0, e[i], z[i]);
+}
+
+static void ml_setup(Problem &P) {
+  const int nlev = P.ml_nlev;
+  P.ml.assign(nlev + 1, Problem::Level());
+  P.ml[0].n = P.n[0];
+  P.ml[0].lmax = P.lam_max[OP_AUG];
+  for (int l = 0; l < nlev; ++l) {
+    const Csr &A = l == 0 ? P.mat[ALFD_A] : P.ml[l].A;
+    const Csr &C = l == 0 ? P.mat[ALFD_C] : P.ml[l].C;
+    Problem::Level &N = P.ml[l + 1];
+    const int64_t n = P.ml[l].n, nc = P.ml_nc[l];
+    const int32_t *agg = P.ml_agg[l];
+    const double *w = P.ml_wgt[l];
+    galerkin(A, agg, w, nc, agg, w, nc, N.A);
+    galerkin(C, nullptr, nullptr, C.nrows, agg, w, nc, N.C);
+    transpose_into(N.C, N.Ct);
+    // P (n x nc, one entry per represented row) and R = P^T
+    N.Pm.nrows = n;
+    N.Pm.ncols = nc;
+    N.Pm.own_rp.assign(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+      if (agg[i] >= 0) {
+        N.Pm.own_col.push_back(agg[i]);
+        N.Pm.own_val.push_back(w ? w[i] : 1.0);
+      }
+      N.Pm.own_rp[i + 1] = (int64_t)N.Pm.own_col.size();
+    }
+    N.Pm.rp = N.Pm.own_rp.data();
+    N.Pm.col = N.Pm.own_col.data();
+    N.Pm.val = N.Pm.own_val.data();
+    transpose_into(N.Pm, N.R);
+    for (Csr *m : {&N.A, &N.C, &N.Ct, &N.Pm, &N.R}) choose_lanes(*m);
+    N.n = nc;
+    N.dinv.assign(nc, 0.0);
+    diag_plus(N.A, N.Ct, P.diag[ALFD_INVW], P.cfg.gamma, nc, N.dinv.data());
+    std::vector<double> v(nc), wv(nc), t;
+    for (int64_t i = 0; i < nc; ++i)
+      v[i] = 1.0 + (double)(((uint64_t)i * 2654435761ull) & 1023ull) * (1.0 / 1024.0);
+    double lam = 0.0;
+    for (int it = 0; it < P.cfg.cheb_power_its; ++it) {
+      const double nv = std::sqrt(dot(nc, v.data(), v.data()));
+      scale(nc, 1.0 / nv, v.data());
+      level_op(P, l + 1, v.data(), wv.data(), t);
+      pmul(nc, N.dinv.data(), wv.data(), wv.data());
+      lam = std::sqrt(dot(nc, wv.data(), wv.data()));
+      v.swap(wv);
+    }
+    N.lmax = lam * P.cfg.cheb_safety;
+  }
 }
 
 // ---- RationalPreconditioner (rational_preconditioner.h:29-63) ----------------
@@ -964,6 +1146,11 @@ typedef struct orc_problem {
   int32_t nranks_emulated;
   int64_t n[ALFD_MAX_BLOCKS];
   const int64_t *part_offsets[ALFD_MAX_BLOCKS];  // optional [nranks+1] per block; NULL = even split
+  int32_t ml_levels;                             // ALFD_PREC_MULTILEVEL: aggregates per level
+  int32_t pad_;
+  const int32_t *ml_agg[ALFD_MAX_LEVELS];
+  const double *ml_weight[ALFD_MAX_LEVELS];
+  int64_t ml_ncoarse[ALFD_MAX_LEVELS];
 } orc_problem;
 
 static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P) {
@@ -1004,6 +1191,13 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
   }
   for (int s = 0; s < ALFD_NSLOTS; ++s)
     if (P.mat[s].present()) orc::choose_lanes(P.mat[s]);
+  P.ml_nlev = op->ml_levels;
+  for (int l = 0; l < op->ml_levels && l < ALFD_MAX_LEVELS; ++l) {
+    P.ml_agg[l] = op->ml_agg[l];
+    P.ml_wgt[l] = op->ml_weight[l];
+    P.ml_nc[l] = op->ml_ncoarse[l];
+  }
+  if (cfg->inner_prec == ALFD_PREC_MULTILEVEL && P.ml_nlev < 1) return ALFD_E_NOT_SETUP;
   P.pt.nranks = op->nranks_emulated > 1 ? op->nranks_emulated : 1;
   if (P.pt.nranks > 1) {
     P.pt.offs.resize(P.nblocks);

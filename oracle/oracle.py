@@ -27,7 +27,9 @@ class _Problem(C.Structure):
     _fields_ = [("mat", _Csr * _abi.NSLOTS), ("diag", C.c_void_p * _abi.NDIAGS),
                 ("nblocks", C.c_int32), ("nranks_emulated", C.c_int32),
                 ("n", C.c_int64 * _abi.ALFD_MAX_BLOCKS),
-                ("part_offsets", C.c_void_p * _abi.ALFD_MAX_BLOCKS)]
+                ("part_offsets", C.c_void_p * _abi.ALFD_MAX_BLOCKS),
+                ("ml_levels", C.c_int32), ("pad_", C.c_int32),
+                ("ml_agg", C.c_void_p * 8), ("ml_weight", C.c_void_p * 8), ("ml_ncoarse", C.c_int64 * 8)]
 
 
 def build():
@@ -104,7 +106,8 @@ def dot(x, y):
 class OracleSystem:
     """One block saddle-point system held by host arrays (kept alive here)."""
 
-    def __init__(self, mats: dict, diags: dict, block_sizes, nranks_emulated=1, part_offsets=None):
+    def __init__(self, mats: dict, diags: dict, block_sizes, nranks_emulated=1, part_offsets=None,
+                 aggregates=None):
         self._keep = (mats, diags)
         self.block_sizes = list(block_sizes)
         p = _Problem()
@@ -124,6 +127,13 @@ class OracleSystem:
                 assert o.size == nranks_emulated + 1
                 self._keep += (o,)
                 p.part_offsets[i] = o.ctypes.data
+        if aggregates:
+            p.ml_levels = len(aggregates)
+            for l, (agg, nc) in enumerate(aggregates):
+                agg = np.ascontiguousarray(agg, np.int32)
+                self._keep += (agg,)
+                p.ml_agg[l] = agg.ctypes.data
+                p.ml_ncoarse[l] = nc
         self._p = p
 
     def _check(self, blocks):
@@ -166,15 +176,15 @@ def rational_system_from_problem(pb) -> OracleSystem:
     return OracleSystem(mats, {}, pb.block_sizes)
 
 
-def system_from_problem(pb, nranks_emulated=1, part_offsets=None) -> OracleSystem:
+def system_from_problem(pb, nranks_emulated=1, part_offsets=None, aggregates=None) -> OracleSystem:
     """Wrap a problems.SyntheticProblem: W^-1 = 1/M_ii^2, Mp lumped inverse."""
     mats = {k: pb.mats[k] for k in ("A", "Ct", "C") if k in pb.mats}
     if "A2" in pb.mats:     # elliptic interface: W^-1 = 1/(M^2)_ii (elliptic_interface.cc:726)
         mats.update({"A2": pb.mats["A2"], "M": pb.mats["M"]})
         return OracleSystem(mats, {_abi.INVW: pb.inv_w_diag_of_mass_squared()}, pb.block_sizes,
-                            nranks_emulated, part_offsets)
+                            nranks_emulated, part_offsets, aggregates)
     diags = {_abi.INVW: pb.inv_w_diag_squared()}
     if "B" in pb.mats:
         mats.update({k: pb.mats[k] for k in ("B", "Bt", "Mp")})
         diags[_abi.MP_LUMPED_INV] = pb.mp_lumped_inv()
-    return OracleSystem(mats, diags, pb.block_sizes, nranks_emulated, part_offsets)
+    return OracleSystem(mats, diags, pb.block_sizes, nranks_emulated, part_offsets, aggregates)

@@ -71,22 +71,47 @@ def case(name):
         cfg.outer_solver = _abi.OUTER_MINRES
         cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 5000, 1e-12, 1e-10)   # MinRes wants a linear SPD preconditioner
         cfg.mp_inner = _abi.Control(_abi.CTRL_REDUCTION, 500, 1e-13, 1e-11)
+    elif name in ("stokes3d_multilevel", "laplace3d_multilevel", "elliptic_modified_multilevel"):
+        # aggregation-multigrid inner preconditioner (ML in the reference)
+        if name.startswith("stokes"):
+            pb = problems.stokes3d_sphere(8, 0)
+            cfg = _abi.default_config(_abi.AL_STOKES)
+        elif name.startswith("laplace"):
+            pb = problems.laplace3d_sphere(16, 1)
+            cfg = _abi.default_config(_abi.AL2)
+            cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
+        else:
+            pb = problems.elliptic_interface2d(64, 16)
+            cfg = _abi.default_config(_abi.AL_ELL_MODIFIED)
+            cfg.gamma, cfg.gamma2 = 10.0, 1e-2
+            cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 100000, 1e-2, 1e-20)
+            cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-10)
+        cfg.inner_prec = _abi.PREC_MULTILEVEL
+        cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
     else:
         raise KeyError(name)
     cfg.inner.max_steps = max(cfg.inner.max_steps, 1000)
     return pb, cfg
 
 
+def aggregates_of(pb, cfg):
+    """Aggregates handed to both the library and the oracle for ALFD_PREC_MULTILEVEL."""
+    if cfg.inner_prec != _abi.PREC_MULTILEVEL:
+        return None
+    return problems.geometric_aggregates(pb, a=2, min_coarse=100)
+
+
 ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes2d_circle", "stokes3d_sphere",
              "stokes3d_restart", "elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3",
-             "rational_minres", "stokes_minres_diag"]
+             "rational_minres", "stokes_minres_diag", "stokes3d_multilevel", "laplace3d_multilevel",
+             "elliptic_modified_multilevel"]
 
 
 def oracle_system(pb, cfg):
     from oracle import oracle
     if cfg.variant == _abi.RATIONAL:
         return oracle.rational_system_from_problem(pb)
-    return oracle.system_from_problem(pb)
+    return oracle.system_from_problem(pb, aggregates=aggregates_of(pb, cfg))
 
 
 def prepared_rhs(osys, pb, cfg):

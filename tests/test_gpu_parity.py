@@ -32,7 +32,8 @@ def ctxs(built):
     def get(name):
         if name not in cache:
             pb, cfg = cases.case(name)
-            cache[name] = (pb, cfg, solver.context_from_problem(pb, cfg), cases.oracle_system(pb, cfg))
+            cache[name] = (pb, cfg, solver.context_from_problem(pb, cfg, aggregates=cases.aggregates_of(pb, cfg)),
+                           cases.oracle_system(pb, cfg))
         return cache[name]
     yield get
     for _, _, c, _ in cache.values():
