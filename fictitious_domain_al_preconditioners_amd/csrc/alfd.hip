@@ -187,7 +187,7 @@ struct alfd_ctx {
   int inner_failures = 0, precond_applications = 0;
   std::vector<double> history;
   // timing
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 = A-SpMV launches only (cheap), 2 = every kernel class
   std::vector<TimedLaunch> timed;
   double t_ms[ALFD_T_NCLASSES] = {0, 0, 0, 0};
   int64_t t_launches[ALFD_T_NCLASSES] = {0, 0, 0, 0};
@@ -310,8 +310,10 @@ struct Timer {
   alfd_ctx *ctx;
   int cls;
   hipEvent_t a = nullptr, b = nullptr;
+  bool on;
   Timer(alfd_ctx *c, int cl, double bytes) : ctx(c), cls(cl) {
-    if (ctx->timing) {
+    on = ctx->timing >= 2 || (ctx->timing == 1 && cl == ALFD_T_SPMV_A);
+    if (on) {
       hipEventCreate(&a);
       hipEventCreate(&b);
       hipEventRecord(a, ctx->stream);
@@ -320,7 +322,7 @@ struct Timer {
     }
   }
   ~Timer() {
-    if (ctx->timing) {
+    if (on) {
       hipEventRecord(b, ctx->stream);
       ctx->timed.push_back({cls, a, b});
     }
@@ -2390,8 +2392,8 @@ int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launc
   HIPC(hipMalloc((void **)&dy, std::max<int64_t>(m.nrows, 1) * sizeof(double)));
   hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, ctx->stream,
                      m.ncols, (int64_t)0, dx);
-  const bool was = ctx->timing;
-  ctx->timing = false;
+  const int was = ctx->timing;
+  ctx->timing = 0;
   for (int i = 0; i < 2; ++i) RC(spmv(ctx, slot, dx, dy, 0));
   hipEvent_t a, b;
   HIPC(hipEventCreate(&a));
@@ -2414,7 +2416,7 @@ int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launc
 
 int alfd_enable_timing(alfd_ctx_t ctx, int on) {
   if (!ctx) return ALFD_E_INVALID;
-  ctx->timing = on != 0;
+  ctx->timing = on < 0 ? 0 : on;
   for (int i = 0; i < ALFD_T_NCLASSES; ++i) ctx->t_ms[i] = 0, ctx->t_launches[i] = 0, ctx->t_bytes[i] = 0;
   return ALFD_OK;
 }

@@ -293,7 +293,7 @@ enum alfd_timing_class {
   ALFD_T_VEC = 3,
   ALFD_T_NCLASSES = 4
 };
-int alfd_enable_timing(alfd_ctx_t ctx, int on);
+int alfd_enable_timing(alfd_ctx_t ctx, int on); /* 0 off, 1 = A-SpMV launches only, 2 = all classes */
 int alfd_get_timing(alfd_ctx_t ctx, double *ms /*[ALFD_T_NCLASSES]*/, int64_t *launches /*[..]*/,
                     double *algorithmic_bytes /*[..]*/);
 

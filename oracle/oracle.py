@@ -57,6 +57,11 @@ def lib():
         l.orc_solve.restype = C.c_int
         l.orc_solve.argtypes = [C.POINTER(_Problem), C.POINTER(_abi.Config), PP, PP, C.POINTER(_abi.Result),
                                 C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        l.orc_open.restype = C.c_void_p
+        l.orc_open.argtypes = [C.POINTER(_Problem), C.POINTER(_abi.Config), C.POINTER(C.c_int)]
+        l.orc_close.argtypes = [C.c_void_p]
+        l.orc_h_precond_apply.restype = C.c_int
+        l.orc_h_precond_apply.argtypes = [C.c_void_p, C.POINTER(_abi.Control), PP, PP, C.POINTER(_abi.Result)]
         l.orc_set_threads.restype = C.c_int
         l.orc_set_threads.argtypes = [C.c_int]
         l.orc_set_row_order.restype = C.c_int
@@ -147,6 +152,26 @@ class OracleSystem:
         res = _abi.Result()
         rc = lib().orc_precond_apply(C.byref(self._p), C.byref(cfg), _blocks(src), _blocks(dst), C.byref(res))
         return rc, dst, res
+
+    def open(self, cfg):
+        """Persistent handle (setup once); use with handle_precond_apply / close_handle."""
+        st = C.c_int(0)
+        h = lib().orc_open(C.byref(self._p), C.byref(cfg), C.byref(st))
+        if not h:
+            raise RuntimeError(f"oracle setup failed with status {st.value}")
+        return C.c_void_p(h)
+
+    def handle_precond_apply(self, h, src, inner=None):
+        src = self._check(src)
+        dst = [np.zeros(n) for n in self.block_sizes]
+        res = _abi.Result()
+        rc = lib().orc_h_precond_apply(h, C.byref(inner) if inner is not None else None, _blocks(src),
+                                       _blocks(dst), C.byref(res))
+        return rc, dst, res
+
+    @staticmethod
+    def close_handle(h):
+        lib().orc_close(h)
 
     def system_apply(self, cfg, src):
         src = self._check(src)
