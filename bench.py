@@ -186,7 +186,7 @@ def main():
             "restart": cfg.restart, "partition": f"row-slabs x{world}",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "spmv_window_kernel<2,8,0> (A, LDS-windowed CSR)", "achieved": achieved,
+            "bound": "hbm", "kernel": "spmv_window_kernel<2,8,0,0> (A, LDS-windowed CSR)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
             "launches": spmv["launches"],

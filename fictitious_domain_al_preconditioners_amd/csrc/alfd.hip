@@ -73,6 +73,7 @@ struct DevCsr {
   int64_t n_halo = 0;
   // LDS-window format (long-row matrices): see spmv_window_kernel
   bool win = false;
+  int tag = 0;  // 1 = multigrid level matrix (separate kernel instantiation for profiling)
   int32_t win_RB = 0, win_maxW = 0;
   int64_t win_nblocks = 0, win_fallback_blocks = 0, win_nseg = 0;
   uint16_t *lcol = nullptr;
@@ -395,14 +396,21 @@ template <int R, int U>
 static void launch_window(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
                           const double *d, double *y2) {
   const size_t lds = (size_t)m.win_maxW * sizeof(double);
-#define ALFD_WIN(EPI)                                                                                  \
-  hipLaunchKernelGGL((spmv_window_kernel<R, U, EPI>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds, \
-                     ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin,      \
+#define ALFD_WIN(EPI, TAG)                                                                              \
+  hipLaunchKernelGGL((spmv_window_kernel<R, U, EPI, TAG>), dim3((unsigned)m.win_nblocks), dim3(kBlock), \
+                     lds, ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin,   \
                      m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2)
-  if (epi == 0) ALFD_WIN(0);
-  else if (epi == 1) ALFD_WIN(1);
-  else if (epi == 2) ALFD_WIN(2);
-  else ALFD_WIN(3);
+  if (m.tag == 0) {
+    if (epi == 0) ALFD_WIN(0, 0);
+    else if (epi == 1) ALFD_WIN(1, 0);
+    else if (epi == 2) ALFD_WIN(2, 0);
+    else ALFD_WIN(3, 0);
+  } else {
+    if (epi == 0) ALFD_WIN(0, 1);
+    else if (epi == 1) ALFD_WIN(1, 1);
+    else if (epi == 2) ALFD_WIN(2, 1);
+    else ALFD_WIN(3, 1);
+  }
 #undef ALFD_WIN
 }
 
@@ -1601,6 +1609,7 @@ static int upload_level(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h) {
   RC(upload_matrix(ctx, kScratchSlot, h.nrows, h.ncols, h.rp.data(), h.col.empty() ? &no_col : h.col.data(),
                    h.val.empty() ? &no_val : h.val.data()));
   dst = ctx->mat[kScratchSlot];
+  dst.tag = 1;
   return ALFD_OK;
 }
 

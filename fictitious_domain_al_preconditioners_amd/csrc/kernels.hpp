@@ -194,7 +194,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
 // Same fma/tree order as spmv_stream_kernel => bit-identical results.
 // Blocks whose window exceeds the LDS budget (blk_W < 0) gather from global
 // memory with the original 32-bit columns.
-template <int R, int U, int EPI>
+// TAG only distinguishes instantiations (fine operator = 0, multigrid level matrices = 1)
+// so that profiler summaries report them separately.
+template <int R, int U, int EPI, int TAG = 0>
 __global__ __launch_bounds__(kBlock) void spmv_window_kernel(
     int64_t nrows, int32_t RB, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
     const uint16_t *__restrict__ lcol, const double *__restrict__ val,
