@@ -2,12 +2,12 @@
 """bench.py -- AL-preconditioned FGMRES throughput on MI355X.
 
 One "step" = one full FGMRES solve (to the prm's stop rule) of the synthetic
-3-D Stokes-immersed system of BASELINE.json configs[3]
+3-D Stokes-immersed system of BASELINE.json configs[3] (N = 74^3 cells: 10.35 M DoF >= 1e7)
 (stokes_immersed_boundary + parameters_stokes_3d.prm),
 with every operator and vector already resident in HBM when the timed region
 starts.  value = outer FGMRES iterations per second over the K timed solves.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n-cells 64]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n-cells 74]
 
 N > 1: launched by torch.distributed.run, one rank per GPU; the SAME global
 problem is row-partitioned over the ranks ("scaling": "strong"), Krylov inner
@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-cells", type=int, default=int(os.environ.get("ALFD_BENCH_NCELLS", "64")))
+    ap.add_argument("--n-cells", type=int, default=int(os.environ.get("ALFD_BENCH_NCELLS", "74")))
     ap.add_argument("--immersed-refine", type=int, default=-1)
     ap.add_argument("--cheb-degree", type=int, default=4)
     ap.add_argument("--inner-max", type=int, default=2000)
