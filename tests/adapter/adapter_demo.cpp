@@ -5,8 +5,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "alfd/dealii_adapter.hpp"
+#include "alfd/dealii_export.hpp"
 #include "mock_dealii.hpp"
 
 extern "C" {
@@ -38,7 +40,7 @@ static mock::SparseMatrix load(void *h, const char *name) {
   return mock::SparseMatrix((size_t)m, (size_t)n, (const long *)rp, col, val);
 }
 
-int main() {
+int main(int argc, char **argv) {
   using namespace alfd::dealii_adapter;
   alfd_synth_params sp;
   std::memset(&sp, 0, sizeof(sp));
@@ -57,6 +59,27 @@ int main() {
     for (size_t i = 0; i < n_l; ++i)
       inv_diagonal[i] = 1. / (mass_matrix.diag_element(i) * mass_matrix.diag_element(i));
 
+    if (argc > 2 && std::string(argv[1]) == "export") {
+      // dump the operators the way a deal.II user would (no GPU needed)
+      alfd_config cfg;
+      alfd_default_config(&cfg, ALFD_AL2);
+      cfg.outer = {ALFD_CTRL_REDUCTION, 1000, 1e-10, 1e-12};
+      cfg.inner.max_steps = 1000;
+      mock::BlockVector rhs({n_u, n_l});
+      int64_t ng;
+      const double *gg;
+      alfd_synth_vector(h, "g", &ng, &gg);
+      for (size_t i = 0; i < n_l; ++i) rhs.block(1)[i] = gg[i];
+      alfd::dealii_export::Writer w(argv[2]);
+      w.matrix(ALFD_A, stiffness_matrix);
+      w.matrix(ALFD_CT, coupling_matrix);
+      w.diag(ALFD_INVW, inv_diagonal);
+      w.rhs(rhs);
+      w.config(cfg);
+      w.close();
+      alfd_synth_free(h);
+      return 0;
+    }
     System sys(0);
     sys.set_matrix(ALFD_A, stiffness_matrix);
     sys.set_matrix(ALFD_CT, coupling_matrix);     // C = transpose_operator(Ct) is derived

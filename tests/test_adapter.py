@@ -32,3 +32,66 @@ def test_adapter_solve_matches_golden(demo):
     gold = json.load(open(os.path.join(HERE, "golden", "solves.json")))["laplace2d_circle"]
     first = p.stdout.splitlines()[0]
     assert f"outer={gold['outer_iterations']} inner={gold['inner_iterations']} " in first, p.stdout
+
+
+def test_cpp_exporter_round_trips_through_the_wire_format(demo, tmp_path):
+    """include/alfd/dealii_export.hpp (driven through the mock SparseMatrix with
+    diagonal-first rows) -> .alfd file -> opfile.load(): identical to the Python-side
+    operators of the same synthetic problem."""
+    import numpy as np
+    from fictitious_domain_al_preconditioners_amd import _abi, opfile, problems
+    path = str(tmp_path / "laplace.alfd")
+    p = subprocess.run([demo, "export", path], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    mats, diags, rhs, x0, cfg = opfile.load(path)
+    pb = problems.laplace2d_circle(64, 4)
+    for slot, name in ((_abi.A, "A"), (_abi.CT, "Ct")):
+        m, ref = mats[slot], pb.mats[name]
+        assert (m.nrows, m.ncols) == (ref.nrows, ref.ncols)
+        assert np.array_equal(m.row_ptr, ref.row_ptr) and np.array_equal(m.col, ref.col)
+        assert np.array_equal(m.val, ref.val)            # columns re-sorted ascending by the exporter
+    assert np.array_equal(diags[_abi.INVW], pb.inv_w_diag_squared())
+    assert x0 is None and [b.size for b in rhs] == pb.block_sizes and np.array_equal(rhs[1], pb.vecs["g"])
+    assert cfg.variant == _abi.AL2 and cfg.outer.tol == 1e-10 and cfg.inner.max_steps == 1000
+
+
+def test_python_save_load_round_trip(tmp_path):
+    import numpy as np
+    from fictitious_domain_al_preconditioners_amd import _abi, opfile, problems
+    pb = problems.stokes3d_sphere(4, 0)
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    mats = {_abi.SLOT_BY_NAME[k]: pb.mats[k] for k in ("A", "Bt", "B", "Ct", "C", "Mp")}
+    diags = {_abi.INVW: pb.inv_w_diag_squared(), _abi.MP_LUMPED_INV: pb.mp_lumped_inv()}
+    rhs = [pb.vecs["f"], pb.vecs["rhs_p"], pb.vecs["g"]]
+    path = str(tmp_path / "s.alfd")
+    opfile.save(path, mats, diags, rhs, cfg, x0=[np.ones(n) for n in pb.block_sizes])
+    m2, d2, r2, x2, c2 = opfile.load(path)
+    assert sorted(m2) == sorted(mats) and bytes(c2) == bytes(cfg)
+    for s in mats:
+        assert np.array_equal(m2[s].col, mats[s].col) and np.array_equal(m2[s].val, mats[s].val)
+    assert all(np.array_equal(a, b) for a, b in zip(r2, rhs)) and all(np.all(b == 1) for b in x2)
+    with open(path, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(ValueError):
+        opfile.load(path)
+
+
+@pytest.mark.gpu
+def test_replay_of_a_dumped_system_matches_golden(demo, tmp_path):
+    from fictitious_domain_al_preconditioners_amd import opfile
+    path = str(tmp_path / "laplace.alfd")
+    assert subprocess.run([demo, "export", path], timeout=120).returncode == 0
+    # the exporter wrote the un-augmented rhs: augment on the GPU like immersed_laplace.cc:900-905
+    from fictitious_domain_al_preconditioners_amd import solver
+    mats, diags, rhs, x0, cfg = opfile.load(path)
+    ctx = solver.Context(0)
+    for slot, m in mats.items():
+        ctx.set_matrix(slot, m)
+    for slot, d in diags.items():
+        ctx.set_diag(slot, d)
+    ctx.configure(cfg)
+    ctx.setup([b.size for b in rhs])
+    x, res = ctx.solve(ctx.augment_rhs(rhs))
+    gold = json.load(open(os.path.join(HERE, "golden", "solves.json")))["laplace2d_circle"]
+    assert (res.outer_iterations, res.inner_iterations) == (gold["outer_iterations"], gold["inner_iterations"])
+    ctx.close()
