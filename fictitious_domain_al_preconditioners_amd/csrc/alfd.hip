@@ -68,6 +68,7 @@ struct DevCsr {
   int32_t *rows = nullptr;
   // multi-rank halo plan
   std::vector<int64_t> send_off, recv_off;  // per peer prefix (size nranks+1)
+  std::vector<int32_t> halo_globals;        // global column id of every halo entry (host)
   int32_t *send_idx = nullptr;              // local indices to pack
   double *send_buf = nullptr, *halo = nullptr;
   int64_t n_halo = 0;
@@ -170,6 +171,9 @@ struct alfd_ctx {
   std::vector<double> ml_wgt[ALFD_MAX_LEVELS];
   int64_t ml_ncoarse[ALFD_MAX_LEVELS] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<MlLevel> ml;
+  std::vector<int64_t> ml_coff[ALFD_MAX_LEVELS];       // rank offsets of the coarse dofs of each level
+  const int64_t *up_col_offsets = nullptr;             // upload_matrix overrides (level matrices)
+  bool up_local_only = false;
   DevCsr rat_mat;                                      // block-diagonal [S_1 .. S_20, M]
   double *rt_r = nullptr, *rt_z = nullptr, *rt_p = nullptr, *rt_Ap = nullptr, *rt_x = nullptr;
   double *rt_dinv = nullptr, *rt_partial = nullptr, *rt_scb = nullptr, *rt_coef = nullptr;
@@ -1300,18 +1304,23 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
   const int32_t *col_up = col;
   std::vector<int32_t> remap;
   m.n_local_cols = (int32_t)ncols;
-  if (ctx->nranks > 1) {
+  if (ctx->nranks > 1 && ctx->up_local_only) {
+    // rank-local operator (multigrid transfers): no halo, but the plan arrays must exist
+    m.send_off.assign(ctx->nranks + 1, 0);
+    m.recv_off.assign(ctx->nranks + 1, 0);
+  } else if (ctx->nranks > 1) {
     if (ctx->part.empty()) return ctx->err = "alfd_set_partition must precede alfd_set_matrix", ALFD_E_INVALID;
     int rb, cb;
     slot_blocks(ctx, slot, &rb, &cb);
-    const std::vector<int64_t> &po = ctx->part[cb];
+    const int64_t *po = ctx->up_col_offsets ? ctx->up_col_offsets : ctx->part[cb].data();
     const int64_t c0 = po[ctx->rank], c1 = po[ctx->rank + 1];
     m.n_local_cols = (int32_t)(c1 - c0);
     std::vector<int32_t> hal;
     remap.resize(m.nnz);
     m.recv_off.assign(ctx->nranks + 1, 0);
-    host_halo_plan(m.nnz, col, po.data(), ctx->nranks, ctx->rank, remap.data(), hal, m.recv_off.data());
+    host_halo_plan(m.nnz, col, po, ctx->nranks, ctx->rank, remap.data(), hal, m.recv_off.data());
     m.n_halo = (int64_t)hal.size();
+    m.halo_globals = hal;
     col_up = remap.data();
     // counts all-to-all through an all-gather of the nranks x nranks matrix
     std::vector<int32_t> cnt_local(ctx->nranks), cnt_all((size_t)ctx->nranks * ctx->nranks);
@@ -1664,25 +1673,74 @@ static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z) {
 
 static int ws_alloc_zero(alfd_ctx *ctx, double **p, int64_t count);
 
+// Aggregate ids over the LOCAL index space [owned | halo] of a matrix' column space:
+// the owned part is given, the halo part is fetched from the owners through the
+// matrix' own halo plan (ids travel as exactly representable doubles).
+static int exchange_ids(alfd_ctx *ctx, DevCsr &m, const std::vector<int32_t> &owned, std::vector<int32_t> &all) {
+  all.assign(owned.begin(), owned.end());
+  if (ctx->nranks == 1) return ALFD_OK;
+  std::vector<double> v(owned.begin(), owned.end());
+  double *d = nullptr;
+  HIPC(hipMalloc((void **)&d, std::max<size_t>(v.size(), 1) * sizeof(double)));
+  HIPC(hipMemcpyAsync(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = ALFD_OK;
+  if (ctx->local || m.n_halo > 0 || m.send_off.back() > 0) rc = halo_exchange(ctx, m, d);
+  if (rc == ALFD_OK && m.n_halo > 0) {
+    std::vector<double> h(m.n_halo);
+    hipMemcpyAsync(h.data(), m.halo, m.n_halo * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    for (double x : h) all.push_back((int32_t)x);
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  return rc;
+}
+
+static int upload_level_part(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h, const int64_t *col_offsets,
+                             bool local_only) {
+  ctx->up_col_offsets = col_offsets;
+  ctx->up_local_only = local_only;
+  const int rc = upload_level(ctx, dst, h);
+  ctx->up_col_offsets = nullptr;
+  ctx->up_local_only = false;
+  return rc;
+}
+
 static int ml_setup(alfd_ctx *ctx) {
   const alfd_config &c = ctx->cfg;
-  if (ctx->nranks > 1) return ctx->err = "multilevel inner preconditioner is single-rank for now", ALFD_E_UNSUPPORTED;
   if (c.ml_smooth_degree < 1 || c.ml_coarse_degree < 1 || !(c.ml_smooth_ratio > 1.0) || !(c.ml_coarse_ratio > 1.0))
     return ctx->err = "bad multilevel parameters", ALFD_E_INVALID;
   int nlev = 0;
   while (nlev < ALFD_MAX_LEVELS && !ctx->ml_agg[nlev].empty()) ++nlev;
   if (nlev == 0) return ctx->err = "alfd_set_aggregates must precede alfd_setup for ALFD_PREC_MULTILEVEL", ALFD_E_NOT_SETUP;
-  if ((int64_t)ctx->ml_agg[0].size() != ctx->n[0]) return ctx->err = "aggregates of level 0 do not match block 0", ALFD_E_INVALID;
-  for (int l = 1; l < nlev; ++l)
-    if ((int64_t)ctx->ml_agg[l].size() != ctx->ml_ncoarse[l - 1])
-      return ctx->err = "aggregates of level " + std::to_string(l) + " do not match the previous level", ALFD_E_INVALID;
+  const int rk = ctx->rank, last = ctx->nblocks - 1;
+  // rank offsets of every level's unknowns: level 0 = block 0, level l+1 = ml_coff[l]
+  std::vector<std::vector<int64_t>> off(nlev + 1);
+  if (ctx->nranks > 1) {
+    off[0] = ctx->part[0];
+    for (int l = 0; l < nlev; ++l) {
+      if ((int)ctx->ml_coff[l].size() != ctx->nranks + 1 || ctx->ml_coff[l].back() != ctx->ml_ncoarse[l])
+        return ctx->err = "alfd_set_aggregate_partition missing or inconsistent for level " + std::to_string(l),
+               ALFD_E_INVALID;
+      off[l + 1] = ctx->ml_coff[l];
+    }
+  } else {
+    off[0] = {0, ctx->n[0]};
+    for (int l = 0; l < nlev; ++l) off[l + 1] = {0, ctx->ml_ncoarse[l]};
+  }
+  for (int l = 0; l < nlev; ++l)
+    if ((int64_t)ctx->ml_agg[l].size() != off[l][rk + 1] - off[l][rk])
+      return ctx->err = "aggregates of level " + std::to_string(l) + " do not match this rank's unknowns", ALFD_E_INVALID;
   ctx->ml.assign(nlev + 1, MlLevel());
-  HostCsr A, C, An, Cn, Ctn, P, R;
+  HostCsr A, C, Ct, An, Cn, Ctn, P, R;
   RC(download_csr(ctx, ctx->mat[ALFD_A], A));
   RC(download_csr(ctx, ctx->mat[ALFD_C], C));
-  int64_t n = ctx->n[0];
+  RC(download_csr(ctx, ctx->mat[ALFD_CT], Ct));
+  const int64_t lam0 = ctx->nranks > 1 ? ctx->part[last][rk] : 0;
+  const int64_t lam_global = ctx->nranks > 1 ? ctx->part[last].back() : ctx->n[last];
   for (int l = 0; l <= nlev; ++l) {
     MlLevel &L = ctx->ml[l];
+    const int64_t n = off[l][rk + 1] - off[l][rk];
     L.n = n;
     L.npad = pad_chunk(n);
     RC(ws_alloc_zero(ctx, &L.r, L.npad));
@@ -1697,10 +1755,11 @@ static int ml_setup(alfd_ctx *ctx) {
     } else {
       RC(ws_alloc_zero(ctx, &L.dinv, L.npad));
       RC(diag_plus_m(ctx, L.A, L.Ct, c.gamma, n, L.dinv));
-      // lambda_max(D^-1 Aug_l): power iteration from the integer-hash vector
+      // lambda_max(D^-1 Aug_l): power iteration from the integer-hash vector (global index)
       double *v = L.t, *wv = L.r;
-      hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
-                         (int64_t)0, v);
+      if (n > 0)
+        hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                           off[l][rk], v);
       double lam = 0;
       for (int it = 0; it < c.cheb_power_its; ++it) {
         RC(dot_async(ctx, L.npad, v, v, S_TMP));
@@ -1719,35 +1778,56 @@ static int ml_setup(alfd_ctx *ctx) {
       HIPC(hipMemsetAsync(L.r, 0, L.npad * sizeof(double), ctx->stream));
     }
     if (l == nlev) break;
-    // next level
-    const int32_t *agg = ctx->ml_agg[l].data();
+    // ---- next level: Galerkin products of this rank's rows
+    const std::vector<int32_t> &aggG = ctx->ml_agg[l];  // owned fine dof -> GLOBAL coarse id (or -1)
     const double *w = ctx->ml_wgt[l].empty() ? nullptr : ctx->ml_wgt[l].data();
-    const int64_t nc = ctx->ml_ncoarse[l];
-    galerkin(A, agg, w, nc, agg, w, nc, An);
-    galerkin(C, nullptr, nullptr, C.nrows, agg, w, nc, Cn);
-    transpose_host(Cn, Ctn);
+    if (w && ctx->nranks > 1) return ctx->err = "weighted aggregates are single-rank for now", ALFD_E_UNSUPPORTED;
+    const int64_t c0 = off[l + 1][rk], nc_loc = off[l + 1][rk + 1] - c0, nc_glob = off[l + 1].back();
+    std::vector<int32_t> agg_rows(n);  // owned fine dof -> LOCAL coarse row
+    for (int64_t i = 0; i < n; ++i) {
+      if (aggG[i] >= 0 && (aggG[i] < c0 || aggG[i] >= c0 + nc_loc))
+        return ctx->err = "an aggregate spans two ranks", ALFD_E_INVALID;
+      agg_rows[i] = aggG[i] < 0 ? -1 : (int32_t)(aggG[i] - c0);
+    }
+    DevCsr &dA = l == 0 ? ctx->mat[ALFD_A] : L.A;
+    DevCsr &dC = l == 0 ? ctx->mat[ALFD_C] : L.C;
+    DevCsr &dCt = l == 0 ? ctx->mat[ALFD_CT] : L.Ct;
+    std::vector<int32_t> aggA, aggC;
+    RC(exchange_ids(ctx, dA, aggG, aggA));   // columns of A_l: [owned | halo of A_l]
+    RC(exchange_ids(ctx, dC, aggG, aggC));   // columns of C_l: [owned | halo of C_l]
+    galerkin(A, agg_rows.data(), w, nc_loc, aggA.data(), w, nc_glob, An);
+    galerkin(C, nullptr, nullptr, C.nrows, aggC.data(), w, nc_glob, Cn);
+    // Ct_{l+1} = P^T Ct_l: rows grouped by aggregate, multiplier columns back to GLOBAL ids
+    std::vector<int32_t> lam_ids((size_t)dCt.n_local_cols + dCt.halo_globals.size());
+    for (int32_t j = 0; j < dCt.n_local_cols; ++j) lam_ids[j] = (int32_t)(lam0 + j);
+    for (size_t j = 0; j < dCt.halo_globals.size(); ++j) lam_ids[dCt.n_local_cols + j] = dCt.halo_globals[j];
+    galerkin(Ct, agg_rows.data(), w, nc_loc, lam_ids.data(), nullptr, lam_global, Ctn);
+    // transfers are rank-local: P (n x nc_loc, one entry per represented row), R = P^T
     P.nrows = n;
-    P.ncols = nc;
+    P.ncols = nc_loc;
     P.rp.assign(n + 1, 0);
     P.col.clear();
     P.val.clear();
     for (int64_t i = 0; i < n; ++i) {
-      if (agg[i] >= 0) {
-        P.col.push_back(agg[i]);
+      if (agg_rows[i] >= 0) {
+        P.col.push_back(agg_rows[i]);
         P.val.push_back(w ? w[i] : 1.0);
       }
       P.rp[i + 1] = (int64_t)P.col.size();
     }
     transpose_host(P, R);
     MlLevel &Nx = ctx->ml[l + 1];
-    RC(upload_level(ctx, Nx.A, An));
-    RC(upload_level(ctx, Nx.C, Cn));
-    RC(upload_level(ctx, Nx.Ct, Ctn));
-    RC(upload_level(ctx, Nx.P, P));
-    RC(upload_level(ctx, Nx.R, R));
-    A = std::move(An);
-    C = std::move(Cn);
-    n = nc;
+    RC(upload_level_part(ctx, Nx.A, An, off[l + 1].data(), false));
+    RC(upload_level_part(ctx, Nx.C, Cn, off[l + 1].data(), false));
+    RC(upload_level_part(ctx, Nx.Ct, Ctn, ctx->nranks > 1 ? ctx->part[last].data() : nullptr, false));
+    RC(upload_level_part(ctx, Nx.P, P, nullptr, true));
+    RC(upload_level_part(ctx, Nx.R, R, nullptr, true));
+    // host copies of the new level in its LOCAL column space, for the next Galerkin step
+    if (l + 1 < nlev) {
+      RC(download_csr(ctx, Nx.A, A));
+      RC(download_csr(ctx, Nx.C, C));
+      RC(download_csr(ctx, Nx.Ct, Ct));
+    }
   }
   return ALFD_OK;
 }
@@ -2206,6 +2286,14 @@ int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t
     ctx->ml_wgt[level].clear();
   ctx->ml_ncoarse[level] = n_coarse;
   for (int l = level + 1; l < ALFD_MAX_LEVELS; ++l) ctx->ml_agg[l].clear(), ctx->ml_wgt[l].clear();
+  ctx->is_setup = false;
+  return ALFD_OK;
+}
+
+int alfd_set_aggregate_partition(alfd_ctx_t ctx, int level, const int64_t *coarse_offsets) {
+  CHECK_CTX();
+  if (level < 0 || level >= ALFD_MAX_LEVELS || !coarse_offsets) return ALFD_E_INVALID;
+  ctx->ml_coff[level].assign(coarse_offsets, coarse_offsets + ctx->nranks + 1);
   ctx->is_setup = false;
   return ALFD_OK;
 }

@@ -58,3 +58,62 @@ def slab_partition_stokes3d(n_cells: int, immersed_refine: int, world: int) -> S
     """The bench workload: 3-D Taylor-Hood + cubed sphere (problems.stokes3d_sphere)."""
     n_lambda = 3 * (6 * 4 ** immersed_refine + 2)
     return slab_partition(3, n_cells, n_lambda, world, ncomp=3, stokes=True)
+
+
+def partitioned_geometric_aggregates(params: dict, plan: SlabPlan, a: int = 2, min_coarse: int = 600,
+                                     max_levels: int = 7):
+    """Geometric aggregates that respect a slab partition: boxes of a^dim nodes are formed
+    inside every rank's slab (z measured from the slab's first plane), coarse unknowns are
+    numbered rank-major, so no aggregate spans two ranks and every level is again a
+    contiguous row partition.  Returns a list over levels of
+        (agg_global, n_coarse_global, coarse_offsets[world+1], fine_offsets[world+1])
+    where agg_global[i] is the GLOBAL coarse id of global fine dof i (or -1).  With
+    world == 1 this is problems.geometric_aggregates()."""
+    dim, ncomp = params["dim"], params["ncomp"]
+    n1 = params["degree"] * params["n_cells"] + 1
+    world = plan.world
+    idx = np.arange(n1 ** dim, dtype=np.int64)
+    coords = np.stack([(idx // n1 ** d) % n1 for d in range(dim)], axis=1)
+    interior = np.all((coords > 0) & (coords < n1 - 1), axis=1)
+    node_off = np.asarray(plan.node_offsets_u, np.int64)
+    rank_of = np.searchsorted(node_off, idx, side="right") - 1
+    plane = n1 ** (dim - 1)
+    zstart = node_off // plane                      # first z-plane (last axis) of every slab
+    cur = coords[interior].copy()
+    cur[:, dim - 1] -= zstart[rank_of[interior]]    # slab-local coordinate along the split axis
+    cur_rank = rank_of[interior]
+    owner = -np.ones(idx.size, np.int64)
+    owner[interior] = np.arange(cur.shape[0])
+    fine_off = node_off * ncomp
+    levels = []
+    first = True
+    while len(levels) < max_levels:
+        box = cur // a
+        span = int(box.max()) + 1
+        key = cur_rank.astype(np.int64)
+        for d in reversed(range(dim)):
+            key = key * span + box[:, d]
+        uniq, inv = np.unique(key, return_inverse=True)       # rank-major, lexicographic inside a rank
+        urank = uniq // (span ** dim)
+        node_agg = np.where(owner >= 0, inv[np.maximum(owner, 0)], -1) if first else inv
+        agg = node_agg[:, None] * ncomp + np.arange(ncomp)[None, :]
+        agg = np.where(node_agg[:, None] < 0, -1, agg).astype(np.int32).ravel()
+        n_coarse = int(uniq.size * ncomp)
+        coff = np.searchsorted(urank, np.arange(world + 1), side="left").astype(np.int64) * ncomp
+        levels.append((agg, n_coarse, coff, fine_off))
+        if n_coarse <= min_coarse or uniq.size == cur.shape[0]:
+            break
+        nxt = np.zeros((uniq.size, dim), np.int64)
+        nxt[inv] = box
+        cur, cur_rank = nxt, urank
+        fine_off = coff
+        first = False
+    return levels
+
+
+def local_aggregates(levels, rank: int):
+    """Per-rank view for Context.set_aggregates / set_aggregate_partition."""
+    out = []
+    for agg, n_coarse, coff, foff in levels:
+        out.append((agg[int(foff[rank]):int(foff[rank + 1])], n_coarse, coff))
+    return out

@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "alfd_get_history", "alfd_spmv", "alfd_dot", "alfd_matrix_lanes", "alfd_bench_spmv",
     "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan", "alfd_local_group_create",
     "alfd_local_group_destroy", "alfd_comm_init_local", "alfd_set_aggregates",
+    "alfd_set_aggregate_partition",
 ]
 
 
@@ -88,6 +89,7 @@ def load_library():
         "alfd_local_group_destroy": (C.c_int, [vp]),
         "alfd_comm_init_local": (C.c_int, [vp, vp, C.c_int]),
         "alfd_set_aggregates": (C.c_int, [vp, C.c_int, i64, vp, vp, i64]),
+        "alfd_set_aggregate_partition": (C.c_int, [vp, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -167,6 +169,10 @@ class Context:
         w = None if weight is None else np.ascontiguousarray(weight, np.float64)
         self._ck(self._lib.alfd_set_aggregates(self._h, level, agg.size, agg.ctypes.data,
                                                None if w is None else w.ctypes.data, int(n_coarse)))
+
+    def set_aggregate_partition(self, level, coarse_offsets):
+        o = np.ascontiguousarray(coarse_offsets, np.int64)
+        self._ck(self._lib.alfd_set_aggregate_partition(self._h, level, o.ctypes.data))
 
     def configure(self, cfg: _abi.Config):
         self.cfg = cfg
@@ -309,8 +315,11 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None) -> Conte
     reference's diagonal choices: W^-1 = 1/M_ii^2 (stokes...:976-978), lumped
     pressure mass (stokes...:946-954).  aggregates: [(agg, n_coarse), ...] for
     ALFD_PREC_MULTILEVEL (problems.geometric_aggregates)."""
-    for level, (agg, nc) in enumerate(aggregates or []):
+    for level, entry in enumerate(aggregates or []):
+        agg, nc = entry[0], entry[1]
         ctx.set_aggregates(level, agg, nc)
+        if len(entry) > 2 and entry[2] is not None:      # (agg_local, n_coarse_global, coarse_offsets)
+            ctx.set_aggregate_partition(level, entry[2])
     ctx.set_matrix(_abi.A, pb.mats["A"])
     ctx.set_matrix(_abi.CT, pb.mats["Ct"])
     ctx.set_matrix(_abi.C_, pb.mats["C"])

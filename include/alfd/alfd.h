@@ -241,6 +241,10 @@ int alfd_set_diag(alfd_ctx_t ctx, int slot, int64_t n, const double *d);
  * P^T (A + gamma Ct invW C) P, kept factored as (P^T A P) + gamma (C P)^T invW (C P). */
 int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t *agg, const double *weight,
                         int64_t n_coarse);
+/* Multi-rank: agg[] holds this rank's unknowns of level l and GLOBAL coarse ids; the coarse
+ * unknowns of each level are numbered rank-major, coarse_offsets[nranks+1] gives the rank
+ * ranges.  An aggregate must not span two ranks. */
+int alfd_set_aggregate_partition(alfd_ctx_t ctx, int level, const int64_t *coarse_offsets);
 int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg);
 void alfd_default_config(alfd_config *cfg, int variant);
 /* Builds transposes, sparse-row views, diag(Aug), lambda_max, halo plans

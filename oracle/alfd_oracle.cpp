@@ -229,6 +229,7 @@ struct Problem {
   const int32_t *ml_agg[ALFD_MAX_LEVELS] = {};
   const double *ml_wgt[ALFD_MAX_LEVELS] = {};
   int64_t ml_nc[ALFD_MAX_LEVELS] = {};
+  const int64_t *ml_off[ALFD_MAX_LEVELS] = {};        // emulated ranks: offsets of level l+1's unknowns
   struct Level {
     Csr A, C, Ct, Pm, R;
     int64_t n = 0;
@@ -724,13 +725,24 @@ static void ml_setup(Problem &P) {
     std::vector<double> v(nc), wv(nc), t;
     for (int64_t i = 0; i < nc; ++i)
       v[i] = 1.0 + (double)(((uint64_t)i * 2654435761ull) & 1023ull) * (1.0 / 1024.0);
+    // rank-ordered sum of the emulated ranks' local canonical dots on this level
+    auto ldot = [&](const double *x, const double *y) {
+      if (P.pt.nranks <= 1 || !P.ml_off[l]) return dot(nc, x, y);
+      double total = 0.0;
+      for (int r = 0; r < P.pt.nranks; ++r) {
+        const int64_t g0 = P.ml_off[l][r], nl = P.ml_off[l][r + 1] - g0;
+        const double d = dot(nl, x + g0, y + g0);
+        total = r == 0 ? d : total + d;
+      }
+      return total;
+    };
     double lam = 0.0;
     for (int it = 0; it < P.cfg.cheb_power_its; ++it) {
-      const double nv = std::sqrt(dot(nc, v.data(), v.data()));
+      const double nv = std::sqrt(ldot(v.data(), v.data()));
       scale(nc, 1.0 / nv, v.data());
       level_op(P, l + 1, v.data(), wv.data(), t);
       pmul(nc, N.dinv.data(), wv.data(), wv.data());
-      lam = std::sqrt(dot(nc, wv.data(), wv.data()));
+      lam = std::sqrt(ldot(wv.data(), wv.data()));
       v.swap(wv);
     }
     N.lmax = lam * P.cfg.cheb_safety;
@@ -1159,6 +1171,7 @@ typedef struct orc_problem {
   const int32_t *ml_agg[ALFD_MAX_LEVELS];
   const double *ml_weight[ALFD_MAX_LEVELS];
   int64_t ml_ncoarse[ALFD_MAX_LEVELS];
+  const int64_t *ml_offsets[ALFD_MAX_LEVELS];    // emulated ranks: [nranks+1] offsets of each coarse level
 } orc_problem;
 
 static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P) {
@@ -1204,6 +1217,7 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
     P.ml_agg[l] = op->ml_agg[l];
     P.ml_wgt[l] = op->ml_weight[l];
     P.ml_nc[l] = op->ml_ncoarse[l];
+    P.ml_off[l] = op->ml_offsets[l];
   }
   if (cfg->inner_prec == ALFD_PREC_MULTILEVEL && P.ml_nlev < 1) return ALFD_E_NOT_SETUP;
   P.pt.nranks = op->nranks_emulated > 1 ? op->nranks_emulated : 1;

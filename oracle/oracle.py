@@ -29,7 +29,8 @@ class _Problem(C.Structure):
                 ("n", C.c_int64 * _abi.ALFD_MAX_BLOCKS),
                 ("part_offsets", C.c_void_p * _abi.ALFD_MAX_BLOCKS),
                 ("ml_levels", C.c_int32), ("pad_", C.c_int32),
-                ("ml_agg", C.c_void_p * 8), ("ml_weight", C.c_void_p * 8), ("ml_ncoarse", C.c_int64 * 8)]
+                ("ml_agg", C.c_void_p * 8), ("ml_weight", C.c_void_p * 8), ("ml_ncoarse", C.c_int64 * 8),
+                ("ml_offsets", C.c_void_p * 8)]
 
 
 def build():
@@ -134,11 +135,16 @@ class OracleSystem:
                 p.part_offsets[i] = o.ctypes.data
         if aggregates:
             p.ml_levels = len(aggregates)
-            for l, (agg, nc) in enumerate(aggregates):
+            for l, entry in enumerate(aggregates):
+                agg, nc = entry[0], entry[1]
                 agg = np.ascontiguousarray(agg, np.int32)
                 self._keep += (agg,)
                 p.ml_agg[l] = agg.ctypes.data
                 p.ml_ncoarse[l] = nc
+                if len(entry) > 2 and entry[2] is not None and nranks_emulated > 1:
+                    off = np.ascontiguousarray(entry[2], np.int64)
+                    self._keep += (off,)
+                    p.ml_offsets[l] = off.ctypes.data
         self._p = p
 
     def _check(self, blocks):

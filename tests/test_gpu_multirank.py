@@ -18,7 +18,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-def _run_ranks(world, n, ref, cfg):
+def _run_ranks(world, n, ref, cfg, levels=None):
     plan = partition.slab_partition_stokes3d(n, ref, world)
     group = solver.LocalGroup(world)
     out = [None] * world
@@ -30,7 +30,7 @@ def _run_ranks(world, n, ref, cfg):
             ctx = solver.Context(0)
             ctx.comm_init_local(group.handle, rank)
             ctx.set_partition(plan.offsets)
-            solver.upload_problem(ctx, pb, cfg)
+            solver.upload_problem(ctx, pb, cfg, partition.local_aggregates(levels, rank) if levels else None)
             rhs = ctx.augment_rhs(cases.rhs_of(pb))
             x, res = ctx.solve(rhs)
             sysx = ctx.system_apply(x)
@@ -94,3 +94,38 @@ def test_partitioned_matches_single_rank_to_rounding(built):
     ctx.close()
     assert out[0]["res"]["outer_iterations"] == res.outer_iterations
     assert np.allclose(out[0]["hist"], h1, rtol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_multilevel_solve_matches_oracle_emulation(built, world):
+    """ALFD_PREC_MULTILEVEL on the row-partitioned path: slab-respecting aggregates,
+    aggregate ids of halo columns fetched through the matrices' halo plans, per-level
+    partitions, rank-local transfers.  Must reproduce the oracle's emulation (which builds
+    ONE global hierarchy from the same aggregates) -- same counts, history within 1e-10."""
+    n, ref = 8, 0
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    cfg.inner.max_steps = 1000
+    cfg.inner_prec = _abi.PREC_MULTILEVEL
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
+    full = problems.stokes3d_sphere(n, ref)
+    plan = partition.slab_partition_stokes3d(n, ref, world)
+    levels = partition.partitioned_geometric_aggregates(full.params, plan, a=2, min_coarse=100)
+    plan, out = _run_ranks(world, n, ref, cfg, levels)
+    osys = oracle.system_from_problem(full, nranks_emulated=world, part_offsets=plan.offsets,
+                                      aggregates=[(a, nc, coff) for a, nc, coff, _ in levels])
+    rc, orhs = osys.augment_rhs(cfg, cases.rhs_of(full))
+    rc, ox, ores, ohist = osys.solve(cfg, orhs)
+    assert rc == 0
+    for r in range(world):
+        res = out[r]["res"]
+        assert res["status"] == 0
+        assert (res["outer_iterations"], res["inner_iterations"], res["mp_iterations"]) == \
+            (ores.outer_iterations, ores.inner_iterations, ores.mp_iterations)
+        assert np.max(np.abs(out[r]["hist"] - ohist) / np.abs(ohist)) <= 1e-10
+    xs = np.concatenate([out[r]["x"][0] for r in range(world)])
+    assert np.allclose(xs, ox[0], rtol=1e-9, atol=1e-10 * np.abs(ox[0]).max())
+    # fewer inner iterations than the single-level sweep on the same partition
+    cfg2 = _abi.default_config(_abi.AL_STOKES)
+    cfg2.inner.max_steps = 1000
+    _, out2 = _run_ranks(world, n, ref, cfg2)
+    assert out[0]["res"]["inner_iterations"] < out2[0]["res"]["inner_iterations"]
