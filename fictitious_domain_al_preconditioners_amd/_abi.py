@@ -51,6 +51,7 @@ class Config(C.Structure):
         ("rho_bound", C.c_double), ("rational", Control),
         ("ml_smooth_degree", C.c_int32), ("ml_coarse_degree", C.c_int32),
         ("ml_smooth_ratio", C.c_double), ("ml_coarse_ratio", C.c_double),
+        ("aug_assembled", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

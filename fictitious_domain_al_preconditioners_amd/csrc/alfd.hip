@@ -548,6 +548,7 @@ static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y) {
   switch (op) {
     case OP_AUG:
       RC(spmv(ctx, ALFD_A, x, y, 0));
+      if (ctx->cfg.aug_assembled) return ALFD_OK;  // operator form: A already holds the AL term
       RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 2, 0.0, w));
       return spmv(ctx, ALFD_CT, ctx->t_lam, y, 1, ctx->cfg.gamma);
     case OP_MP:
@@ -854,8 +855,12 @@ static int system_apply(alfd_ctx *ctx, const double *x, double *y) {
     const double *x0 = x + off[0];
     double *y0 = y + off[0];
     RC(spmv(ctx, ALFD_A, x0, y0, 0));
-    RC(spmv(ctx, ALFD_C, x0, y + off[last], 3, 0.0, w, ctx->t_lam));
-    RC(spmv(ctx, ALFD_CT, ctx->t_lam, y0, 1, c.gamma));
+    if (c.aug_assembled) {
+      RC(spmv(ctx, ALFD_C, x0, y + off[last], 0));
+    } else {
+      RC(spmv(ctx, ALFD_C, x0, y + off[last], 3, 0.0, w, ctx->t_lam));
+      RC(spmv(ctx, ALFD_CT, ctx->t_lam, y0, 1, c.gamma));
+    }
     if (ctx->nblocks == 3) {
       RC(spmv(ctx, ALFD_BT, x + off[1], y0, 1, 1.0));
       RC(spmv(ctx, ALFD_B, x0, y + off[1], 0));
@@ -1627,6 +1632,7 @@ static int level_op(alfd_ctx *ctx, int l, const double *x, double *y) {
   if (l == 0) return op_apply(ctx, OP_AUG, x, y);
   MlLevel &L = ctx->ml[l];
   RC(spmv_m(ctx, L.A, ALFD_T_SPMV_OTHER, x, y, 0));
+  if (ctx->cfg.aug_assembled) return ALFD_OK;
   RC(spmv_m(ctx, L.C, ALFD_T_SPMV_OTHER, x, ctx->t_lam, 2, 0.0, ctx->diag[ALFD_INVW]));
   return spmv_m(ctx, L.Ct, ALFD_T_SPMV_OTHER, ctx->t_lam, y, 1, ctx->cfg.gamma);
 }
@@ -1754,7 +1760,7 @@ static int ml_setup(alfd_ctx *ctx) {
       L.lmax = ctx->lam_max[OP_AUG];
     } else {
       RC(ws_alloc_zero(ctx, &L.dinv, L.npad));
-      RC(diag_plus_m(ctx, L.A, L.Ct, c.gamma, n, L.dinv));
+      RC(diag_plus_m(ctx, L.A, L.Ct, c.aug_assembled ? 0.0 : c.gamma, n, L.dinv));
       // lambda_max(D^-1 Aug_l): power iteration from the integer-hash vector (global index)
       double *v = L.t, *wv = L.r;
       if (n > 0)
@@ -2002,7 +2008,9 @@ static int setup(alfd_ctx *ctx) {
     return ALFD_OK;
   }
   // diag(Aug) = diag(A) + gamma sum_k w_k Ct_ik^2 (no product matrix is formed)
-  RC(diag_plus(ctx, ALFD_A, ALFD_CT, c.gamma, ctx->n[0], ctx->dinv_aug));
+  if (c.aug_assembled && is_elliptic(c.variant))
+    return ctx->err = "aug_assembled (operator form) is implemented for the AL2 / Stokes variants", ALFD_E_UNSUPPORTED;
+  RC(diag_plus(ctx, ALFD_A, ALFD_CT, c.aug_assembled ? 0.0 : c.gamma, ctx->n[0], ctx->dinv_aug));
   if (ell) {
     // diag(A22_aug) = diag(A2) + gamma2 sum_k w_k M_ik^2
     RC(ws_alloc_zero(ctx, &ctx->dinv_a22, pad_chunk(ctx->n[1])));

@@ -227,6 +227,9 @@ struct Params {
   double imm_lo = 0.25, imm_hi = 0.75;
   int imm_cells = 8;
   double beta2 = 0.0;
+  // also emit G_ij = int_Gamma phi_i phi_j on the background space (the particle-assembled
+  // AL term of the "operator form", immersed_laplace.cc:659-705)
+  int want_surface_mass = 0;
   // row ranges of this process (multi-GPU row partition); -1 = everything.
   // u/p ranges are in NODES (z-slabs of the lexicographic numbering), l in dofs.
   int64_t u_node0 = -1, u_node1 = -1, p_node0 = -1, p_node1 = -1, l0 = -1, l1 = -1;
@@ -644,7 +647,8 @@ void build_immersed(const Params &P, const Grid &g, Problem &pb) {
   const int dim = g.dim, nc = P.ncomp;
   Immersed im = P.immersed_kind == 1 ? make_box_2d(P) : (dim == 2) ? make_circle(P) : make_cubed_sphere(P);
   const int64_t nl = im.nnodes();
-  std::vector<Triplet> tc, tm, tk;
+  std::vector<Triplet> tc, tm, tk, tg;
+  std::vector<std::pair<int64_t, double>> qnodes;
   std::vector<double> gint(nl, 0.0);  // int chi_k
   const int p = g.p;
   immersed_quadrature(im, P.coupling_nq, [&](const QPoint &qp) {
@@ -673,6 +677,7 @@ void build_immersed(const Params &P, const Grid &g, Problem &pb) {
       shape1d(p, s - c, v1[a], d1[a]);
     }
     int l[3] = {0, 0, 0}, j[3] = {0, 0, 0};
+    qnodes.clear();
     for (l[2] = 0; l[2] <= (dim == 3 ? p : 0); ++l[2])
       for (l[1] = 0; l[1] <= p; ++l[1])
         for (l[0] = 0; l[0] <= p; ++l[0]) {
@@ -682,7 +687,11 @@ void build_immersed(const Params &P, const Grid &g, Problem &pb) {
           if (g.boundary(j)) continue;
           const int64_t jn = g.node(j);
           for (int a = 0; a < im.cell_nodes; ++a) tc.push_back({cn[a], jn, phi * sh[a] * JxW});
+          if (P.want_surface_mass) qnodes.emplace_back(jn, phi);
         }
+    if (P.want_surface_mass)
+      for (const auto &na : qnodes)
+        for (const auto &nb : qnodes) tg.push_back({na.first, nb.first, na.second * nb.second * JxW});
   });
   Csr Cs = csr_from_triplets(nl, g.nnodes, tc);  // scalar C
   Csr Ms = csr_from_triplets(nl, nl, tm);
@@ -716,6 +725,10 @@ void build_immersed(const Params &P, const Grid &g, Problem &pb) {
   for (int64_t k = 0; k < nl; ++k)
     for (int b = 0; b < nc; ++b) gv[k * nc + b] = P.embedded_value[b] * gint[k];
   pb.vecs["n_lambda_global"] = {(double)(nl * nc)};
+  if (P.want_surface_mass) {
+    Csr Gs = csr_from_triplets(g.nnodes, g.nnodes, tg);
+    pb.mats["G"] = expand(Gs, g.nnodes);
+  }
   if (P.immersed_kind == 1) {
     // elliptic_interface: A2 = (beta_2 - beta_1) (grad, grad) on Omega_2 (elliptic...:681),
     // f2 = int (f_2 - f) chi_k with f_2 - f = 1 (parameters_modified.prm:25-29)
@@ -846,6 +859,7 @@ struct alfd_synth_params {
   int64_t u_node0, u_node1, p_node0, p_node1, l0, l1;
   int32_t immersed_kind, imm_cells;
   double imm_lo, imm_hi, beta2;
+  int32_t want_surface_mass, pad_;
 };
 
 void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
@@ -880,6 +894,7 @@ void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
   P.imm_lo = sp->imm_lo;
   P.imm_hi = sp->imm_hi;
   P.beta2 = sp->beta2;
+  P.want_surface_mass = sp->want_surface_mass;
   if (!generate(*pb)) {
     if (err && errlen > 0) std::snprintf(err, errlen, "%s", pb->err.c_str());
     delete pb;

@@ -34,6 +34,7 @@ class _Params(C.Structure):
         ("l0", C.c_int64), ("l1", C.c_int64),
         ("immersed_kind", C.c_int32), ("imm_cells", C.c_int32),
         ("imm_lo", C.c_double), ("imm_hi", C.c_double), ("beta2", C.c_double),
+        ("want_surface_mass", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -161,8 +162,12 @@ class SyntheticProblem:
             return [n_u, self.mats["B"].ncols and self.mats["Mp"].ncols, n_l]
         return [n_u, n_l]
 
+    inv_w_override: object = None   # set by a caller that wants another W^-1 (e.g. 1/M_ii, operator form)
+
     def inv_w_diag_squared(self) -> np.ndarray:
         """W^-1 = 1 / M_ii^2 (stokes_immersed_boundary.cc:976-978, immersed_laplace.cc:866-869)."""
+        if self.inv_w_override is not None:
+            return np.asarray(self.inv_w_override, np.float64)
         d = self.mats["M"].diagonal(self.row_ranges[4] if self.row_ranges else 0)
         return 1.0 / (d * d)
 
@@ -187,7 +192,7 @@ class SyntheticProblem:
 def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False, grad_div=False,
              gamma_grad_div=0.0, beta=1.0, center=(0.5, 0.5, 0.5), radius=0.2, immersed_refine=3,
              coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0),
-             row_ranges=None, immersed_box=None, beta2=0.0) -> SyntheticProblem:
+             row_ranges=None, immersed_box=None, beta2=0.0, surface_mass=False) -> SyntheticProblem:
     """immersed_box = (lo, hi, cells): the immersed domain is the 2-D box [lo,hi]^2
     with cells^2 Q1 cells (volume coupling, elliptic_interface); beta2 scales "A2".
     row_ranges = (u_node0, u_node1, p_node0, p_node1, l0, l1): generate only this
@@ -206,6 +211,7 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     p.radius, p.immersed_refine, p.coupling_nq = radius, immersed_refine, coupling_nq
     rr = tuple(int(v) for v in row_ranges) if row_ranges is not None else (-1,) * 6
     p.u_node0, p.u_node1, p.p_node0, p.p_node1, p.l0, p.l1 = rr
+    p.want_surface_mass = int(surface_mass)
     if immersed_box is not None:
         p.immersed_kind, p.imm_lo, p.imm_hi, p.imm_cells = 1, float(immersed_box[0]), float(immersed_box[1]), int(immersed_box[2])
         p.beta2 = beta2
@@ -219,7 +225,7 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     owner = _NativeHandle(h)
     pb = SyntheticProblem(params=params, _handle=owner,
                           row_ranges=rr if row_ranges is not None else None)
-    for name in ("A", "B", "Bt", "Mp", "Ct", "C", "M", "K", "A2"):
+    for name in ("A", "B", "Bt", "Mp", "Ct", "C", "M", "K", "A2", "G"):
         nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
         rp, col, val = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
         if lib.alfd_synth_matrix(owner.ptr, name.encode(), C.byref(nr), C.byref(nc), C.byref(nnz),
@@ -238,12 +244,24 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
 
 # ---------------------------------------------------------------------------
 # The BASELINE.json configs as concrete synthetic instances.
-def laplace2d_circle(n_cells=64, immersed_refine=5, coupling_nq=3) -> SyntheticProblem:
+def laplace2d_circle(n_cells=64, immersed_refine=5, coupling_nq=3, surface_mass=False) -> SyntheticProblem:
     """cfg 1: immersed_laplace 2-D, parameters/circle/Circle_parameters_f0_g1.prm
     (f = 0, g = 1, R = 0.2, centre (0.4, 0.4)), Q1 background on [0,1]^2."""
     return generate(dim=2, degree=1, ncomp=1, n_cells=n_cells, center=(0.4, 0.4, 0.0), radius=0.2,
                     immersed_refine=immersed_refine, coupling_nq=coupling_nq,
-                    body_force=(0.0,), embedded_value=(1.0,))
+                    body_force=(0.0,), embedded_value=(1.0,), surface_mass=surface_mass)
+
+
+def operator_form(pb: SyntheticProblem, gamma: float = 10.0):
+    """The "operator form" of immersed_laplace.cc:653-705: gamma <- gamma / h_immersed,
+    A <- A + gamma int_Gamma phi_i phi_j (needs generate(surface_mass=True)), W^-1 = 1/M_ii.
+    Returns (A_assembled Csr, gamma_h, inv_w)."""
+    xyz = pb.vecs["immersed_xyz"].reshape(-1, 3)
+    h = float(np.linalg.norm(xyz[1] - xyz[0]))                      # segment length of the circle mesh
+    gamma_h = gamma / h
+    a = (pb.mats["A"].to_scipy() + gamma_h * pb.mats["G"].to_scipy()).tocsr()
+    a.sort_indices()
+    return Csr.from_scipy(a), gamma_h, 1.0 / pb.mats["M"].diagonal()
 
 
 def laplace3d_sphere(n_cells=128, immersed_refine=5, coupling_nq=3) -> SyntheticProblem:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 3
+#define ALFD_ABI_VERSION 4
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -160,6 +160,11 @@ typedef struct alfd_config {
   int32_t ml_coarse_degree;   /* Chebyshev degree that stands in for the coarsest-level solve */
   double ml_smooth_ratio;     /* smoother targets [lambda_max/ratio, lambda_max] */
   double ml_coarse_ratio;     /* same for the coarsest level */
+  /* "operator form" (immersed_laplace.cc:653-705, 880-882; `Use operator version = true`):
+   * the caller has assembled the AL term into A (gamma/h * int_Gamma phi_i phi_j), so
+   * Aug = A and only the preconditioner and the rhs augmentation use gamma and invW. */
+  int32_t aug_assembled;
+  int32_t reserved;
 } alfd_config;
 
 typedef struct alfd_result {

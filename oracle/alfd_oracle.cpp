@@ -305,6 +305,8 @@ struct InnerOp {
       spmv(P.mat[ALFD_A], x, y, 0, 0.0);
     } else if (kind == OP_MAT) {
       spmv(*mat, x, y, 0, 0.0);
+    } else if (kind == OP_AUG && P.cfg.aug_assembled) {
+      spmv(P.mat[ALFD_A], x, y, 0, 0.0);  // operator form: A already holds the AL term
     } else if (kind == OP_AUG) {
       const Csr &C = P.mat[ALFD_C];
       spmv(P.mat[ALFD_A], x, y, 0, 0.0);
@@ -552,7 +554,7 @@ static void setup(Problem &P) {
     return;
   }
   P.dinv_aug.assign(P.n[0], 0.0);
-  diag_plus(P.mat[ALFD_A], P.mat[ALFD_CT], w, P.cfg.gamma, P.n[0], P.dinv_aug.data());
+  diag_plus(P.mat[ALFD_A], P.mat[ALFD_CT], w, P.cfg.aug_assembled ? 0.0 : P.cfg.gamma, P.n[0], P.dinv_aug.data());
   if (is_elliptic(P.cfg.variant)) {
     P.dinv_a22.assign(P.n[1], 0.0);
     diag_plus(P.mat[ALFD_A2], P.mat[ALFD_M], w, P.cfg.gamma2, P.n[1], P.dinv_a22.data());
@@ -636,6 +638,7 @@ static void level_op(Problem &P, int l, const double *x, double *y, std::vector<
   const Csr &C = l == 0 ? P.mat[ALFD_C] : P.ml[l].C;
   const Csr &Ct = l == 0 ? P.mat[ALFD_CT] : P.ml[l].Ct;
   spmv(A, x, y, 0, 0.0);
+  if (P.cfg.aug_assembled) return;
   t.resize(C.nrows);
   spmv(C, x, t.data(), 0, 0.0);
   pmul(C.nrows, P.diag[ALFD_INVW], t.data(), t.data());
@@ -721,7 +724,7 @@ static void ml_setup(Problem &P) {
     for (Csr *m : {&N.A, &N.C, &N.Ct, &N.Pm, &N.R}) choose_lanes(*m);
     N.n = nc;
     N.dinv.assign(nc, 0.0);
-    diag_plus(N.A, N.Ct, P.diag[ALFD_INVW], P.cfg.gamma, nc, N.dinv.data());
+    diag_plus(N.A, N.Ct, P.diag[ALFD_INVW], P.cfg.aug_assembled ? 0.0 : P.cfg.gamma, nc, N.dinv.data());
     std::vector<double> v(nc), wv(nc), t;
     for (int64_t i = 0; i < nc; ++i)
       v[i] = 1.0 + (double)(((uint64_t)i * 2654435761ull) & 1023ull) * (1.0 / 1024.0);
@@ -898,9 +901,11 @@ static int system_apply(Problem &P, const double *x, double *y) {
     const Csr &C = P.mat[ALFD_C];
     spmv(P.mat[ALFD_A], x0, y0, 0, 0.0);
     spmv(C, x0, yl, 0, 0.0);                            // y_lambda = C x0
-    std::vector<double> t(C.nrows);
-    pmul(C.nrows, w, yl, t.data());
-    spmv(P.mat[ALFD_CT], t.data(), y0, 1, c.gamma);     // + gamma Ct invW C x0
+    if (!c.aug_assembled) {
+      std::vector<double> t(C.nrows);
+      pmul(C.nrows, w, yl, t.data());
+      spmv(P.mat[ALFD_CT], t.data(), y0, 1, c.gamma);   // + gamma Ct invW C x0
+    }
     if (P.nblocks == 3) {
       spmv(P.mat[ALFD_BT], x + P.off[1], y0, 1, 1.0);   // + Bt x1
       spmv(P.mat[ALFD_B], x0, y + P.off[1], 0, 0.0);    // y1 = B x0

@@ -71,6 +71,16 @@ def case(name):
         cfg.outer_solver = _abi.OUTER_MINRES
         cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 5000, 1e-12, 1e-10)   # MinRes wants a linear SPD preconditioner
         cfg.mp_inner = _abi.Control(_abi.CTRL_REDUCTION, 500, 1e-13, 1e-11)
+    elif name == "laplace2d_operator_form":
+        # immersed_laplace "Use operator version = true" + "Use diagonal inverse = true"
+        # (immersed_laplace.cc:653-705, 855-858): AL term assembled into A, gamma = 10/h, W^-1 = 1/M_ii
+        pb = problems.laplace2d_circle(64, 4, surface_mass=True)
+        a_op, gamma_h, inv_w = problems.operator_form(pb)
+        pb.mats = dict(pb.mats, A=a_op)
+        pb.inv_w_override = inv_w
+        cfg = _abi.default_config(_abi.AL2)
+        cfg.gamma, cfg.aug_assembled = gamma_h, 1
+        cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
     elif name in ("stokes3d_multilevel", "laplace3d_multilevel", "elliptic_modified_multilevel"):
         # aggregation-multigrid inner preconditioner (ML in the reference)
         if name.startswith("stokes"):
@@ -104,7 +114,7 @@ def aggregates_of(pb, cfg):
 ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes2d_circle", "stokes3d_sphere",
              "stokes3d_restart", "elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3",
              "rational_minres", "stokes_minres_diag", "stokes3d_multilevel", "laplace3d_multilevel",
-             "elliptic_modified_multilevel"]
+             "elliptic_modified_multilevel", "laplace2d_operator_form"]
 
 
 def oracle_system(pb, cfg):
