@@ -122,7 +122,10 @@ def config_from_prm(tree: dict) -> tuple[_abi.Config, dict]:
         if info["solver"] != "augmented":
             info["unsupported"].append(f"Solver = {info['solver']} (non-AL branch, out of scope)")
         if info["use_operator_form"]:
-            info["unsupported"].append("Use operator version = true (particle-assembled AL term; gamma *= 1/h)")
+            # immersed_laplace.cc:653-705: the caller assembles gamma/h int_Gamma phi_i phi_j into A
+            # and passes gamma = 10/h_immersed (h is a mesh quantity the .prm does not hold)
+            cfg.aug_assembled = 1
+            info["gamma_needs_h_scaling"] = True
         if not info["diagonal_W"]:
             info["unsupported"].append("Use diagonal inverse = false (UMFPACK (M^-1)^2)")
         return cfg, info

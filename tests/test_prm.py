@@ -70,7 +70,8 @@ def test_immersed_laplace_and_elliptic_sections():
                     " subsection Schur solver control\n set Max steps = 1000\n set Tolerance = 1.e-10\n end\nend\n")
     cfg, info = prm.config_from_prm(lap)
     assert cfg.variant == _abi.AL2 and cfg.gamma == 10.0 and cfg.outer.tol == 1e-10 and cfg.outer.reduce == 1e-12
-    assert len(info["unsupported"]) == 2         # operator form + UMFPACK W are flagged, not guessed
+    assert cfg.aug_assembled == 1 and info["gamma_needs_h_scaling"]      # operator form: supported
+    assert len(info["unsupported"]) == 1         # the UMFPACK W is flagged, not guessed
     ell = prm.parse("subsection Elliptic Interface Problem\n set Beta_2 = 10\n subsection AL preconditioner\n"
                     " set Use modified AL preconditioner = true\n set gamma fluid = 10\n set gamma solid = 1e-2\n end\n"
                     " subsection Inner solver control\n set Max steps = 100000\n set Reduction = 1.e-20\n set Tolerance = 1.e-2\n end\n"
