@@ -199,7 +199,7 @@ struct alfd_ctx {
   double t_bytes[ALFD_T_NCLASSES] = {0, 0, 0, 0};
   std::vector<void *> allocs;
   int spmv_stream_R = 2, spmv_stream_U = 8, spmv_nt = 0, spmv_grid_mult = 8;  // tunables (env ALFD_SPMV_*)
-  int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8;
+  int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
   int64_t ntot() const { return off[nblocks]; }
 };
 
@@ -403,7 +403,7 @@ static void launch_window(alfd_ctx *ctx, const DevCsr &m, const double *x, doubl
 #define ALFD_WIN(EPI, TAG)                                                                              \
   hipLaunchKernelGGL((spmv_window_kernel<R, U, EPI, TAG>), dim3((unsigned)m.win_nblocks), dim3(kBlock), \
                      lds, ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin,   \
-                     m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2)
+                     m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->win_xcd)
   if (m.tag == 0) {
     if (epi == 0) ALFD_WIN(0, 0);
     else if (epi == 1) ALFD_WIN(1, 0);
@@ -2125,6 +2125,7 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB")) ctx->win_RB = std::max(4, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_GAP")) ctx->win_gap = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("ALFD_SPMV_WINDOW_XCD")) ctx->win_xcd = std::atoi(e);
   *out = ctx;
   return ALFD_OK;
 }

@@ -203,11 +203,20 @@ __global__ __launch_bounds__(kBlock) void spmv_window_kernel(
     const int32_t *__restrict__ blk_seg_begin, const int32_t *__restrict__ blk_W,
     const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
     const double *__restrict__ x, const double *__restrict__ x_halo, int32_t n_local,
-    double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2) {
+    double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2,
+    int xcd_remap) {
   extern __shared__ double xs[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t b = blockIdx.x;
+  // XCD-aware block order: workgroups with equal blockIdx % 8 share an XCD (and its L2),
+  // so each XCD is given a CONTIGUOUS run of row blocks -- neighbouring blocks share
+  // most of their x window, which then hits in that XCD's L2 (bijective remap for any
+  // grid size; affects speed only).
+  int64_t b = blockIdx.x;
+  if (xcd_remap) {
+    const int64_t nwg = gridDim.x, q = nwg / 8, rm = nwg % 8, xcd = b % 8, idx = b / 8;
+    b = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + idx;
+  }
   const int32_t W = blk_W[b];
   if (W >= 0) {
     const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
