@@ -72,6 +72,7 @@ struct DevCsr {
   int32_t *send_idx = nullptr;              // local indices to pack
   double *send_buf = nullptr, *halo = nullptr;
   int64_t n_halo = 0;
+  std::vector<void *> owned;  // device arrays of this matrix (released on re-upload / destroy)
   // LDS-window format (long-row matrices): see spmv_window_kernel
   bool win = false;
   int tag = 0;  // 1 = multigrid level matrix (separate kernel instantiation for profiling)
@@ -303,6 +304,19 @@ static int dev_alloc_zero(alfd_ctx *ctx, double **p, int64_t count) {
   RC(dev_alloc(ctx, p, count));
   HIPC(hipMemsetAsync(*p, 0, std::max<int64_t>(count, 1) * sizeof(double), ctx->stream));
   return ALFD_OK;
+}
+
+template <class T>
+static int csr_alloc(alfd_ctx *ctx, DevCsr &m, T **p, int64_t count) {
+  void *q = nullptr;
+  HIPC(hipMalloc(&q, std::max<int64_t>(count, 1) * sizeof(T)));
+  m.owned.push_back(q);
+  *p = static_cast<T *>(q);
+  return ALFD_OK;
+}
+static void csr_free(DevCsr &m) {
+  for (void *q : m.owned) hipFree(q);
+  m = DevCsr();
 }
 
 static inline int grid_for_rows(int64_t nrows, int L) {
@@ -1261,11 +1275,11 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
   m.win_nblocks = nb;
   m.win_fallback_blocks = fb;
   m.win_nseg = (int64_t)seg_col.size();
-  RC(dev_alloc(ctx, &m.lcol, m.nnz));
-  RC(dev_alloc(ctx, &m.blk_seg_begin, nb + 1));
-  RC(dev_alloc(ctx, &m.blk_W, nb));
-  RC(dev_alloc(ctx, &m.seg_col, m.win_nseg));
-  RC(dev_alloc(ctx, &m.seg_off, m.win_nseg));
+  RC(csr_alloc(ctx, m, &m.lcol, m.nnz));
+  RC(csr_alloc(ctx, m, &m.blk_seg_begin, nb + 1));
+  RC(csr_alloc(ctx, m, &m.blk_W, nb));
+  RC(csr_alloc(ctx, m, &m.seg_col, m.win_nseg));
+  RC(csr_alloc(ctx, m, &m.seg_off, m.win_nseg));
   HIPC(hipMemcpyAsync(m.lcol, lcol.data(), m.nnz * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipMemcpyAsync(m.blk_seg_begin, seg_begin.data(), (nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipMemcpyAsync(m.blk_W, blkW.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1279,7 +1293,7 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
 static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, const int64_t *rp,
                          const int32_t *col, const double *val) {
   DevCsr &m = ctx->mat[slot];
-  m = DevCsr();
+  csr_free(m);  // a re-upload releases the previous arrays of this slot
   m.nrows = nrows;
   m.ncols = ncols;
   m.nnz = rp[nrows];
@@ -1291,12 +1305,14 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     int64_t mine[2] = {m.nnz, nonempty};
     std::vector<int64_t> all(2 * (size_t)ctx->nranks);
     int64_t *d_m = nullptr, *d_a = nullptr;
-    RC(dev_alloc(ctx, &d_m, 2));
-    RC(dev_alloc(ctx, &d_a, 2 * (int64_t)ctx->nranks));
+    HIPC(hipMalloc((void **)&d_m, 2 * sizeof(int64_t)));
+    HIPC(hipMalloc((void **)&d_a, 2 * sizeof(int64_t) * ctx->nranks));
     HIPC(hipMemcpyAsync(d_m, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
     RC(comm_allgather(ctx, d_m, d_a, sizeof(mine)));
     HIPC(hipMemcpyAsync(all.data(), d_a, all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
+    hipFree(d_m);
+    hipFree(d_a);
     int64_t gn = 0, ge = 0;
     for (int p = 0; p < ctx->nranks; ++p) gn += all[2 * p], ge += all[2 * p + 1];
     DevCsr tmp;
@@ -1331,8 +1347,8 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     std::vector<int32_t> cnt_local(ctx->nranks), cnt_all((size_t)ctx->nranks * ctx->nranks);
     for (int p = 0; p < ctx->nranks; ++p) cnt_local[p] = (int32_t)(m.recv_off[p + 1] - m.recv_off[p]);
     int32_t *d_cl = nullptr, *d_ca = nullptr;
-    RC(dev_alloc(ctx, &d_cl, ctx->nranks));
-    RC(dev_alloc(ctx, &d_ca, (int64_t)ctx->nranks * ctx->nranks));
+    HIPC(hipMalloc((void **)&d_cl, sizeof(int32_t) * ctx->nranks));
+    HIPC(hipMalloc((void **)&d_ca, sizeof(int32_t) * ctx->nranks * ctx->nranks));
     HIPC(hipMemcpyAsync(d_cl, cnt_local.data(), ctx->nranks * 4, hipMemcpyHostToDevice, ctx->stream));
     RC(comm_allgather(ctx, d_cl, d_ca, (size_t)ctx->nranks * 4));
     HIPC(hipMemcpyAsync(cnt_all.data(), d_ca, cnt_all.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1343,24 +1359,28 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     const int64_t nsend = m.send_off.back();
     // exchange requested ids: I send my halo id list slices, receive what peers want from me
     int32_t *d_req = nullptr, *d_want = nullptr;
-    RC(dev_alloc(ctx, &d_req, m.n_halo));
-    RC(dev_alloc(ctx, &d_want, nsend));
+    HIPC(hipMalloc((void **)&d_req, sizeof(int32_t) * std::max<int64_t>(m.n_halo, 1)));
+    HIPC(hipMalloc((void **)&d_want, sizeof(int32_t) * std::max<int64_t>(nsend, 1)));
     HIPC(hipMemcpyAsync(d_req, hal.data(), m.n_halo * 4, hipMemcpyHostToDevice, ctx->stream));
     // I send my wanted-id list slices (grouped by owner), I receive what peers want from me
     RC(comm_alltoallv(ctx, d_req, m.recv_off.data(), d_want, m.send_off.data(), sizeof(int32_t)));
     std::vector<int32_t> want(nsend);
     HIPC(hipMemcpyAsync(want.data(), d_want, nsend * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
+    hipFree(d_cl);
+    hipFree(d_ca);
+    hipFree(d_req);
+    hipFree(d_want);
     // the column space of this matrix is block cb; my owned range there starts at c0
     for (auto &g : want) g = (int32_t)(g - c0);
-    RC(dev_alloc(ctx, &m.send_idx, nsend));
+    RC(csr_alloc(ctx, m, &m.send_idx, nsend));
     HIPC(hipMemcpyAsync(m.send_idx, want.data(), nsend * 4, hipMemcpyHostToDevice, ctx->stream));
-    RC(dev_alloc(ctx, &m.send_buf, nsend));
-    RC(dev_alloc(ctx, &m.halo, m.n_halo));
+    RC(csr_alloc(ctx, m, &m.send_buf, nsend));
+    RC(csr_alloc(ctx, m, &m.halo, m.n_halo));
     HIPC(hipStreamSynchronize(ctx->stream));
   }
-  RC(dev_alloc(ctx, &m.col, m.nnz));
-  RC(dev_alloc(ctx, &m.val, m.nnz));
+  RC(csr_alloc(ctx, m, &m.col, m.nnz));
+  RC(csr_alloc(ctx, m, &m.val, m.nnz));
   HIPC(hipMemcpyAsync(m.col, col_up, m.nnz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipMemcpyAsync(m.val, val, m.nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   if (m.sparse) {
@@ -1375,15 +1395,15 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     for (size_t i = 0; i < rows.size(); ++i) crp[i] = rp[rows[i]];
     crp[rows.size()] = m.nnz;
     m.n_list = (int64_t)rows.size();
-    RC(dev_alloc(ctx, &m.rows, m.n_list));
-    RC(dev_alloc(ctx, &m.rp, m.n_list + 1));
+    RC(csr_alloc(ctx, m, &m.rows, m.n_list));
+    RC(csr_alloc(ctx, m, &m.rp, m.n_list + 1));
     HIPC(hipMemcpyAsync(m.rows, rows.data(), m.n_list * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIPC(hipMemcpyAsync(m.rp, crp.data(), (m.n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
                         ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
   } else {
     m.n_list = nrows;
-    RC(dev_alloc(ctx, &m.rp, nrows + 1));
+    RC(csr_alloc(ctx, m, &m.rp, nrows + 1));
     HIPC(hipMemcpyAsync(m.rp, rp, (nrows + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
   }
   HIPC(hipStreamSynchronize(ctx->stream));
@@ -1503,6 +1523,12 @@ static int power_iteration(alfd_ctx *ctx, int op) {
 // Chebyshev post-smoothing of the residual; the coarsest level is "solved" by a
 // high-degree Chebyshev sweep.  Every piece is a fixed polynomial in SPD
 // operators, so the preconditioner is a fixed SPD operator and plain CG applies.
+static void free_levels(alfd_ctx *ctx) {
+  for (MlLevel &L : ctx->ml)
+    for (DevCsr *m : {&L.A, &L.C, &L.Ct, &L.P, &L.R}) csr_free(*m);
+  ctx->ml.clear();
+}
+
 static int download_csr(alfd_ctx *ctx, const DevCsr &m, HostCsr &h) {
   h.nrows = m.nrows;
   h.ncols = m.ncols;
@@ -1622,7 +1648,9 @@ static int upload_level(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h) {
   static const double no_val = 0;
   RC(upload_matrix(ctx, kScratchSlot, h.nrows, h.ncols, h.rp.data(), h.col.empty() ? &no_col : h.col.data(),
                    h.val.empty() ? &no_val : h.val.data()));
-  dst = ctx->mat[kScratchSlot];
+  csr_free(dst);
+  dst = std::move(ctx->mat[kScratchSlot]);
+  ctx->mat[kScratchSlot] = DevCsr();
   dst.tag = 1;
   return ALFD_OK;
 }
@@ -1737,6 +1765,7 @@ static int ml_setup(alfd_ctx *ctx) {
   for (int l = 0; l < nlev; ++l)
     if ((int64_t)ctx->ml_agg[l].size() != off[l][rk + 1] - off[l][rk])
       return ctx->err = "aggregates of level " + std::to_string(l) + " do not match this rank's unknowns", ALFD_E_INVALID;
+  free_levels(ctx);
   ctx->ml.assign(nlev + 1, MlLevel());
   HostCsr A, C, Ct, An, Cn, Ctn, P, R;
   RC(download_csr(ctx, ctx->mat[ALFD_A], A));
@@ -1967,7 +1996,9 @@ static int setup(alfd_ctx *ctx) {
       // upload through the generic path into a scratch slot object
       RC(upload_matrix(ctx, kScratchSlot, npl * kRatSystems, npl * kRatSystems, rp.data(), col.data(),
                        val.data()));
-      ctx->rat_mat = ctx->mat[kScratchSlot];
+      csr_free(ctx->rat_mat);
+      ctx->rat_mat = std::move(ctx->mat[kScratchSlot]);
+      ctx->mat[kScratchSlot] = DevCsr();
     }
     const int64_t nt = npl * kRatSystems;
     RC(ws_alloc_zero(ctx, &ctx->rt_r, nt));
@@ -2030,7 +2061,7 @@ static int setup(alfd_ctx *ctx) {
     RC(power_iteration(ctx, OP_AUG));
   }
   ctx->lambda_max = ctx->lam_max[c.variant == ALFD_AL_ELL_IDEAL ? OP_AUG2 : OP_AUG];
-  ctx->ml.clear();
+  free_levels(ctx);
   if (c.inner_prec == ALFD_PREC_MULTILEVEL) {
     if (c.variant == ALFD_AL_ELL_IDEAL)
       return ctx->err = "multilevel inner preconditioner: not for the 2x2 block CG of the ideal variant", ALFD_E_UNSUPPORTED;
@@ -2135,6 +2166,9 @@ int alfd_destroy(alfd_ctx_t ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   flush_timers(ctx);
+  free_levels(ctx);
+  csr_free(ctx->rat_mat);
+  for (DevCsr &m : ctx->mat) csr_free(m);
   for (void *p : ctx->ws_allocs) hipFree(p);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->sc_host) hipHostFree(ctx->sc_host);
@@ -2247,6 +2281,11 @@ int alfd_set_diag(alfd_ctx_t ctx, int slot, int64_t n, const double *d) {
   CHECK_CTX();
   if (slot < 0 || slot >= ALFD_NDIAGS || n < 0 || (n > 0 && !d)) return ALFD_E_INVALID;
   ctx->is_setup = false;
+  if (ctx->diag[slot]) {
+    ctx->allocs.erase(std::remove(ctx->allocs.begin(), ctx->allocs.end(), (void *)ctx->diag[slot]), ctx->allocs.end());
+    hipFree(ctx->diag[slot]);
+    ctx->diag[slot] = nullptr;
+  }
   RC(dev_alloc_zero(ctx, &ctx->diag[slot], pad_chunk(n)));
   HIPC(hipMemcpyAsync(ctx->diag[slot], d, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));

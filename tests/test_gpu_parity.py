@@ -255,6 +255,27 @@ def test_error_behaviour(ctxs):
     fresh.close()
 
 
+def test_no_device_memory_growth_across_reupload_and_setup(built):
+    """Re-uploading every slot and repeating alfd_setup (which rebuilds the multigrid
+    hierarchy) must release the previous device arrays."""
+    import torch
+    pb = problems.stokes3d_sphere(16, 1)
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    cfg.inner.max_steps = 2000
+    cfg.inner_prec = _abi.PREC_MULTILEVEL
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
+    aggs = problems.geometric_aggregates(pb, a=2)
+    ctx = solver.Context(0)
+    used = []
+    for _ in range(5):
+        solver.upload_problem(ctx, pb, cfg, aggs)
+        ctx.solve(ctx.augment_rhs(cases.rhs_of(pb)))
+        free, total = torch.cuda.mem_get_info(0)
+        used.append((total - free) / 1e6)
+    ctx.close()
+    assert used[-1] - used[1] < 16.0, used          # MB
+
+
 def test_properties_at_bench_scale(built):
     """BASELINE.json's full size -- the bench workload itself: N = 74 Taylor-Hood, 10.35 M
     DoF, 1.78 G nnz (far beyond what the oracle finishes in seconds), checked through
