@@ -69,6 +69,16 @@ class Result(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class MatrixInfo(C.Structure):
+    _fields_ = [
+        ("lanes", C.c_int32), ("windowed", C.c_int32), ("value_indexed", C.c_int32), ("reserved", C.c_int32),
+        ("nnz", C.c_int64), ("window_blocks", C.c_int64), ("window_fallback_blocks", C.c_int64),
+        ("value_indexed_blocks", C.c_int64), ("value_indexed_nnz", C.c_int64),
+        ("dictionary_entries", C.c_int64), ("value_escapes", C.c_int64),
+        ("algorithmic_bytes", C.c_double), ("streamed_bytes", C.c_double),
+    ]
+
+
 def default_config(variant=AL_STOKES) -> Config:
     """Same defaults as alfd_default_config(): the reference's solver knobs
     (parameters_stokes_3d.prm:17-24,150-157; immersed_laplace.cc:907; elliptic...:863)."""

@@ -79,7 +79,22 @@ struct DevCsr {
   int32_t win_RB = 0, win_maxW = 0;
   int64_t win_nblocks = 0, win_fallback_blocks = 0, win_nseg = 0;
   uint16_t *lcol = nullptr;
+  // value-indexed blocks (see spmv_window_kernel): 8-bit dictionary index per entry
+  bool vi = false;
+  uint8_t *vidx = nullptr;
+  int32_t *blk_dict_off = nullptr, *blk_dict_n = nullptr;
+  double *dict = nullptr;
+  int64_t vi_blocks = 0, vi_nnz = 0, vi_dict_total = 0, vi_escapes = 0;
   int32_t *blk_seg_begin = nullptr, *blk_W = nullptr, *seg_col = nullptr, *seg_off = nullptr;
+  // bytes the kernel in use moves per launch (format bytes, x read once)
+  double streamed_bytes(bool use_vi) const {
+    const double vec = (double)(n_list + 1) * 8.0 + (double)n_list * 8.0 + (double)(sparse ? n_list : ncols) * 8.0;
+    if (!win) return (double)nnz * 12.0 + vec;
+    const double meta = (double)win_nblocks * 8.0 + (double)win_nseg * 8.0;
+    if (!(vi && use_vi)) return (double)nnz * 10.0 + vec + meta;
+    return (double)vi_nnz * 3.0 + (double)vi_escapes * 11.0 + (double)(nnz - vi_nnz - vi_escapes) * 10.0 + vec + meta + (double)vi_dict_total * 8.0 +
+           (double)win_nblocks * 8.0;
+  }
   double algorithmic_bytes() const {
     // nnz*(8+4) + (nrows+1)*8 + nrows*8 + ncols*8  (x read once)
     return (double)nnz * 12.0 + (double)(n_list + 1) * 8.0 + (double)n_list * 8.0 +
@@ -200,6 +215,11 @@ struct alfd_ctx {
   double t_bytes[ALFD_T_NCLASSES] = {0, 0, 0, 0};
   std::vector<void *> allocs;
   int spmv_stream_R = 2, spmv_stream_U = 8, spmv_nt = 0, spmv_grid_mult = 8;  // tunables (env ALFD_SPMV_*)
+  int spmv_group_R = 4, spmv_group_U = 4;  // batch shape of the short-row window kernel
+  bool vi_off = false;                      // alfd_bench_spmv_format: time the plain 10 B/nnz kernel on a value-indexed matrix
+  int vi_rows_R = 4, vi_rows_J = 2;         // row-batched VI kernel shape (ALFD_SPMV_VI_R=0: stream-ordered VI kernel)
+  int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
+  int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
   int64_t ntot() const { return off[nblocks]; }
 };
@@ -413,11 +433,36 @@ static bool launch_stream_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, do
 template <int R, int U>
 static void launch_window(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
                           const double *d, double *y2) {
-  const size_t lds = (size_t)m.win_maxW * sizeof(double);
+  const size_t lds = (size_t)(m.win_maxW + (m.vi && !ctx->vi_off ? 256 : 0)) * sizeof(double);
 #define ALFD_WIN(EPI, TAG)                                                                              \
   hipLaunchKernelGGL((spmv_window_kernel<R, U, EPI, TAG>), dim3((unsigned)m.win_nblocks), dim3(kBlock), \
                      lds, ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin,   \
                      m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->win_xcd)
+  const bool vi = m.vi && !ctx->vi_off;
+  if (vi && ctx->vi_rows_R > 0) {
+    const int RR = ctx->vi_rows_R, JJ = ctx->vi_rows_J;
+#define ALFD_VI(RV, JV, EPI)                                                                                  \
+  hipLaunchKernelGGL((spmv_window_vi_kernel<RV, JV, EPI>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds,  \
+                     ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin, m.blk_W,     \
+                     m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, m.vidx, m.blk_dict_off, \
+                     m.blk_dict_n, m.dict, m.win_maxW)
+#define ALFD_VI_E(RV, JV)              \
+  if (RR == RV && JJ == JV) {          \
+    if (epi == 0) ALFD_VI(RV, JV, 0);  \
+    else if (epi == 1) ALFD_VI(RV, JV, 1); \
+    else if (epi == 2) ALFD_VI(RV, JV, 2); \
+    else ALFD_VI(RV, JV, 3);           \
+    return;                            \
+  }
+    ALFD_VI_E(4, 3) ALFD_VI_E(2, 4) ALFD_VI_E(4, 4)
+    if (epi == 0) ALFD_VI(4, 2, 0);  // default shape
+    else if (epi == 1) ALFD_VI(4, 2, 1);
+    else if (epi == 2) ALFD_VI(4, 2, 2);
+    else ALFD_VI(4, 2, 3);
+    return;
+#undef ALFD_VI_E
+#undef ALFD_VI
+  }
   if (m.tag == 0) {
     if (epi == 0) ALFD_WIN(0, 0);
     else if (epi == 1) ALFD_WIN(1, 0);
@@ -432,12 +477,51 @@ static void launch_window(alfd_ctx *ctx, const DevCsr &m, const double *x, doubl
 #undef ALFD_WIN
 }
 
+template <int L, int R, int U>
+static void launch_window_group(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi,
+                                double alpha, const double *d, double *y2) {
+  const size_t lds = (size_t)m.win_maxW * sizeof(double);
+#define ALFD_WING(EPI, TAG)                                                                               \
+  hipLaunchKernelGGL((spmv_window_group_kernel<L, R, U, EPI, TAG>), dim3((unsigned)m.win_nblocks),       \
+                     dim3(kBlock), lds, ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val,        \
+                     m.blk_seg_begin, m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, \
+                     d, y2)
+  if (m.tag == 0) {
+    if (epi == 0) ALFD_WING(0, 0);
+    else if (epi == 1) ALFD_WING(1, 0);
+    else if (epi == 2) ALFD_WING(2, 0);
+    else ALFD_WING(3, 0);
+  } else {
+    if (epi == 0) ALFD_WING(0, 1);
+    else if (epi == 1) ALFD_WING(1, 1);
+    else if (epi == 2) ALFD_WING(2, 1);
+    else ALFD_WING(3, 1);
+  }
+#undef ALFD_WING
+}
+
+template <int L>
+static bool launch_window_group_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi,
+                                   double alpha, const double *d, double *y2) {
+  const int R = ctx->spmv_group_R, U = ctx->spmv_group_U;
+#define ALFD_RU(RR, UU) \
+  if (R == RR && U == UU) return launch_window_group<L, RR, UU>(ctx, m, x, y, epi, alpha, d, y2), true
+  ALFD_RU(4, 4); ALFD_RU(2, 4); ALFD_RU(4, 2); ALFD_RU(8, 4); ALFD_RU(8, 2);
+#undef ALFD_RU
+  return false;
+}
+
 static bool launch_window_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi,
                              double alpha, const double *d, double *y2) {
+  if (m.L == 32) return launch_window_group_RU<32>(ctx, m, x, y, epi, alpha, d, y2);
+  if (m.L == 16) return launch_window_group_RU<16>(ctx, m, x, y, epi, alpha, d, y2);
+  if (m.L == 8) return launch_window_group_RU<8>(ctx, m, x, y, epi, alpha, d, y2);
+  if (m.L != 64) return false;
   const int R = ctx->spmv_stream_R, U = ctx->spmv_stream_U;
 #define ALFD_RU(RR, UU) \
   if (R == RR && U == UU) return launch_window<RR, UU>(ctx, m, x, y, epi, alpha, d, y2), true
   ALFD_RU(1, 4); ALFD_RU(2, 4); ALFD_RU(2, 8); ALFD_RU(4, 2); ALFD_RU(4, 4); ALFD_RU(4, 8); ALFD_RU(8, 4);
+  ALFD_RU(1, 8); ALFD_RU(1, 16); ALFD_RU(2, 16);
 #undef ALFD_RU
   return false;
 }
@@ -1191,12 +1275,24 @@ static void host_halo_plan(int64_t nnz, const int32_t *col, const int64_t *col_o
 
 // Build the LDS-window format of a long-row matrix (host, multi-threaded).
 // col: column indices in the LOCAL index space [local | halo].
-static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col) {
-  const int RB = ctx->win_RB, maxW = ctx->win_maxW, GAP = ctx->win_gap;
+static int short_row_block(const alfd_ctx *ctx, int L) {
+  return L == 64 ? ctx->win_RB : std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / L);
+}
+static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col, const double *val,
+                        bool slot_is_user) {
+  // short rows: larger row blocks, so a window serves about as many entries as for L = 64
+  const int RB = short_row_block(ctx, m.L);
+  const int maxW = ctx->win_maxW, GAP = ctx->win_gap;
   const int64_t nb = (m.nrows + RB - 1) / RB;
   if (nb == 0 || nb > 2147483000LL) return ALFD_OK;
   std::vector<uint16_t> lcol(m.nnz);
   std::vector<int32_t> blkW(nb), blk_nseg(nb);
+  // value dictionaries: long-row fine operators only (level matrices are Galerkin products)
+  const bool want_vi = ctx->win_vi && m.L == 64 && slot_is_user;
+  std::vector<uint8_t> vidx(want_vi ? m.nnz : 0);
+  std::vector<int32_t> blk_dn(nb, -1);
+  std::vector<std::vector<double>> t_dict(want_vi ? nb : 0);
+  std::vector<int64_t> t_escapes(64, 0);
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::vector<int32_t>> t_seg_col(T), t_seg_off(T);
   std::vector<std::thread> th;
@@ -1254,6 +1350,67 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
         blkW[b] = W;
         blk_nseg[b] = nseg;
         for (int64_t k = k0; k < k1; ++k) lcol[k] = (uint16_t)pos[col[k] - clo];
+        if (want_vi) {
+          // open-addressing table over the 64-bit patterns, with counts.  Up to 256 distinct
+          // values: plain dictionary.  Up to kMaxDistinct: the 255 most frequent values get
+          // codes 0..254 and code 255 is an escape (the kernel reads the 8-byte value), as
+          // long as escapes stay below 1/8 of the block's entries.  Beyond that: raw block.
+          constexpr int kTab = 4096, kMaxDistinct = 1024;
+          std::vector<uint64_t> keys(kTab);
+          std::vector<int16_t> ids(kTab, (int16_t)-1);
+          std::vector<double> all_vals;
+          std::vector<int32_t> counts;
+          std::vector<int16_t> first_id(k1 - k0);
+          bool ok = true;
+          for (int64_t k = k0; k < k1 && ok; ++k) {
+            uint64_t bits;
+            std::memcpy(&bits, &val[k], 8);
+            uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 52);
+            for (;;) {
+              if (ids[h] < 0) {
+                if ((int)all_vals.size() == kMaxDistinct) {
+                  ok = false;
+                  break;
+                }
+                keys[h] = bits;
+                ids[h] = (int16_t)all_vals.size();
+                all_vals.push_back(val[k]);
+                counts.push_back(0);
+                break;
+              }
+              if (keys[h] == bits) break;
+              h = (h + 1) & (kTab - 1);
+            }
+            if (ok) {
+              first_id[k - k0] = ids[h];
+              ++counts[ids[h]];
+            }
+          }
+          std::vector<double> &dv = t_dict[b];
+          if (ok && all_vals.size() <= 256) {
+            dv = all_vals;
+            for (int64_t k = k0; k < k1; ++k) vidx[k] = (uint8_t)first_id[k - k0];
+            blk_dn[b] = (int32_t)dv.size();
+          } else if (ok) {
+            std::vector<int32_t> order(all_vals.size());
+            for (size_t q = 0; q < order.size(); ++q) order[q] = (int32_t)q;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t c) { return counts[a] > counts[c]; });
+            std::vector<int16_t> code(all_vals.size(), (int16_t)255);
+            int64_t covered = 0;
+            for (int q = 0; q < 255; ++q) {
+              code[order[q]] = (int16_t)q;
+              covered += counts[order[q]];
+              dv.push_back(all_vals[order[q]]);
+            }
+            if ((k1 - k0 - covered) * 8 <= (k1 - k0)) {
+              for (int64_t k = k0; k < k1; ++k) vidx[k] = (uint8_t)code[first_id[k - k0]];
+              blk_dn[b] = 255 | kDictEscape;
+              t_escapes[t] += k1 - k0 - covered;
+            } else {
+              dv.clear();
+            }
+          }
+        }
       }
     });
   for (auto &x : th) x.join();
@@ -1287,6 +1444,35 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
   HIPC(hipMemcpyAsync(m.seg_off, seg_off.data(), m.win_nseg * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));
   m.win = true;
+  if (want_vi) {
+    std::vector<int32_t> doff(nb, 0);
+    std::vector<double> dict;
+    int64_t nvb = 0, nvn = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      doff[b] = (int32_t)dict.size();
+      if (blk_dn[b] < 0) continue;
+      dict.insert(dict.end(), t_dict[b].begin(), t_dict[b].end());
+      ++nvb;
+      nvn += rp[std::min<int64_t>((b + 1) * RB, m.nrows)] - rp[b * RB];
+    }
+    for (int64_t e : t_escapes) m.vi_escapes += e;
+    nvn -= m.vi_escapes;
+    if (nvb * 2 > nb && dict.size() < 2000000000ull) {  // worthwhile: most blocks are dictionary-coded
+      RC(csr_alloc(ctx, m, &m.vidx, m.nnz));
+      RC(csr_alloc(ctx, m, &m.blk_dict_off, nb));
+      RC(csr_alloc(ctx, m, &m.blk_dict_n, nb));
+      RC(csr_alloc(ctx, m, &m.dict, (int64_t)dict.size()));
+      HIPC(hipMemcpyAsync(m.vidx, vidx.data(), m.nnz, hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.blk_dict_off, doff.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.blk_dict_n, blk_dn.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipMemcpyAsync(m.dict, dict.data(), dict.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIPC(hipStreamSynchronize(ctx->stream));
+      m.vi = true;
+      m.vi_blocks = nvb;
+      m.vi_nnz = nvn;
+      m.vi_dict_total = (int64_t)dict.size();
+    }
+  }
   return ALFD_OK;
 }
 
@@ -1409,8 +1595,11 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
   HIPC(hipStreamSynchronize(ctx->stream));
   // the windowed kernel launches one workgroup per row block: only for matrices with
   // enough row blocks to fill the chip (256 CUs x several workgroups)
-  if (ctx->win_enable && m.L == 64 && !m.sparse && m.nnz > 0 && m.nrows >= (int64_t)ctx->win_RB * 2048)
-    RC(build_window(ctx, m, rp, col_up));
+  const bool win_long = m.L == 64 && m.nrows >= (int64_t)ctx->win_RB * 2048;
+  const bool win_short = ctx->win_short_scale > 0 && m.L >= 8 && m.L < 64 &&
+                         m.nrows >= (int64_t)short_row_block(ctx, m.L) * 1024;
+  if (ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0)
+    RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot));
   m.present = true;
   return ALFD_OK;
 }
@@ -2155,6 +2344,12 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW")) ctx->win_enable = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB")) ctx->win_RB = std::max(4, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
+  if (const char *e = std::getenv("ALFD_SPMV_VI_R")) ctx->vi_rows_R = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_VI_J")) ctx->vi_rows_J = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_VALUE_INDEX")) ctx->win_vi = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_GROUP_R")) ctx->spmv_group_R = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_GROUP_U")) ctx->spmv_group_U = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_WINDOW_SHORT")) ctx->win_short_scale = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_GAP")) ctx->win_gap = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_XCD")) ctx->win_xcd = std::atoi(e);
   *out = ctx;
@@ -2556,6 +2751,37 @@ int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launc
   hipFree(dy);
   if (ms_per_launch) *ms_per_launch = (double)ms / reps;
   if (bytes) *bytes = m.algorithmic_bytes();
+  return ALFD_OK;
+}
+
+int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value_index, double *ms_per_launch,
+                           double *streamed_bytes) {
+  CHECK_CTX();
+  if (slot < 0 || slot >= ALFD_NSLOTS || !ctx->mat[slot].present) return ALFD_E_INVALID;
+  ctx->vi_off = !use_value_index;
+  const int rc = alfd_bench_spmv(ctx, slot, reps, ms_per_launch, nullptr);
+  ctx->vi_off = false;
+  if (streamed_bytes) *streamed_bytes = ctx->mat[slot].streamed_bytes(use_value_index != 0);
+  return rc;
+}
+
+int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
+  CHECK_CTX();
+  if (slot < 0 || slot >= ALFD_NSLOTS || !ctx->mat[slot].present || !out) return ALFD_E_INVALID;
+  const DevCsr &m = ctx->mat[slot];
+  std::memset(out, 0, sizeof(*out));
+  out->lanes = m.L;
+  out->windowed = m.win ? 1 : 0;
+  out->value_indexed = m.vi ? 1 : 0;
+  out->nnz = m.nnz;
+  out->window_blocks = m.win_nblocks;
+  out->window_fallback_blocks = m.win_fallback_blocks;
+  out->value_indexed_blocks = m.vi_blocks;
+  out->value_indexed_nnz = m.vi_nnz;
+  out->dictionary_entries = m.vi_dict_total;
+  out->value_escapes = m.vi_escapes;
+  out->algorithmic_bytes = m.algorithmic_bytes();
+  out->streamed_bytes = m.streamed_bytes(true);
   return ALFD_OK;
 }
 

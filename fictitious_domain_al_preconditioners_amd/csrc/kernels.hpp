@@ -42,6 +42,71 @@ __device__ __forceinline__ double block_reduce_256(double v, double *lds4) {
 }
 
 // --------------------------------------------------------------------------
+// Several 64-lane trees at once, on the vector ALU only (no LDS-pipe shuffles).
+// The canonical tree adds partner lanes l^32, l^16, l^8, l^4, l^2, l^1 in that
+// order.  v_permlane32_swap / v_permlane16_swap exchange half-waves / 16-lane rows
+// between two registers, so the first steps of two (four) rows cost one add and
+// leave the rows packed side by side; the last four steps are DPP moves inside
+// 16-lane rows and serve all packed rows together.  Same pairs, same order =>
+// same bits as group_reduce<64>.
+__device__ __forceinline__ double dpp_xor_mov(double v, int which) {
+  int lo = __double2loint(v), hi = __double2hiint(v), rl, rh;
+  if (which == 8) {
+    rl = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);  // row_ror:8
+    rh = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
+  } else if (which == 4) {
+    rl = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0x5, false);   // row_shl:4 -> banks 0,2
+    rl = __builtin_amdgcn_update_dpp(rl, lo, 0x114, 0xf, 0xa, false);  // row_shr:4 -> banks 1,3
+    rh = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0x5, false);
+    rh = __builtin_amdgcn_update_dpp(rh, hi, 0x114, 0xf, 0xa, false);
+  } else if (which == 2) {
+    rl = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    rh = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false);
+  } else {
+    rl = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    rh = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+  }
+  return __hiloint2double(rh, rl);
+}
+// a -> [a_lo | b_lo], b -> [a_hi | b_hi]  (32-lane halves)
+__device__ __forceinline__ void swap32(double &a, double &b) {
+  auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)h[0], (int)l[0]);
+  b = __hiloint2double((int)h[1], (int)l[1]);
+}
+// odd 16-lane rows of a <-> even rows of b
+__device__ __forceinline__ void swap16(double &a, double &b) {
+  auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)h[0], (int)l[0]);
+  b = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double row16_tree(double v) {
+  v = v + dpp_xor_mov(v, 8);
+  v = v + dpp_xor_mov(v, 4);
+  v = v + dpp_xor_mov(v, 2);
+  v = v + dpp_xor_mov(v, 1);
+  return v;
+}
+// Trees of 4 rows; the result of row q sits in the 16-lane row kRow4Pos(q).
+__device__ __forceinline__ double reduce_rows4(double a0, double a1, double a2, double a3) {
+  swap32(a0, a1);
+  double p = a0 + a1;  // [row0 | row1], step l^32 done
+  swap32(a2, a3);
+  double q = a2 + a3;  // [row2 | row3]
+  swap16(p, q);
+  return row16_tree(p + q);  // 16-lane rows: row0, row2, row1, row3
+}
+// Trees of 2 rows: row 0 in lanes 0..31, row 1 in lanes 32..63.
+__device__ __forceinline__ double reduce_rows2(double a0, double a1) {
+  swap32(a0, a1);
+  double p = a0 + a1, q = p;
+  swap16(p, q);  // p = rows [0,0,2,2], q = rows [1,1,3,3] of the old p
+  return row16_tree(p + q);
+}
+
+// --------------------------------------------------------------------------
 // CSR SpMV, L lanes per row, 256/L rows per workgroup, grid-stride over row
 // groups so that the resident workgroups sweep a compact moving window of rows
 // (x re-use out of L2 / Infinity Cache).
@@ -297,6 +362,277 @@ __global__ __launch_bounds__(kBlock) void spmv_window_kernel(
         const int dsh = rel[i] & 63;
         double s = __shfl(acc[i], (lane + dsh) & 63, 64);
         s = group_reduce<64>(s);
+        if (lane == 0) {
+          if (EPI == 0)
+            y[r] = s;
+          else if (EPI == 1)
+            y[r] = fma(alpha, s, y[r]);
+          else if (EPI == 2)
+            y[r] = d[r] * s;
+          else {
+            y[r] = s;
+            y2[r] = d[r] * s;
+          }
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// Value-indexed blocks: finite-element matrices on the reference's uniformly refined
+// hyper_cube grids repeat a few hundred distinct entry values.  At upload each row block
+// whose entries take <= 256 distinct bit patterns gets a private dictionary (stored once,
+// staged into LDS next to the x window) and an 8-bit code per entry, so the stream is
+// 2 B (window column) + 1 B (value code) = 3 B/nnz instead of 10.  The looked-up double
+// is the stored one bit for bit, so results do not change.  Blocks with somewhat more
+// values keep the 255 most frequent in the dictionary and mark the rest with an escape
+// code; blocks beyond that keep streaming the 8-byte values.
+//
+// Row-batched window kernel for value-indexed matrices.  With 3 B/nnz the stream
+// is no longer HBM-bound but latency-bound, so the kernel is organised to keep
+// many independent loads in flight and to spend few instructions per entry:
+// a wave takes R consecutive rows; lane l reads entries k0_i + l + 64 j of row i
+// -- exactly the canonical lane assignment, so there is no rotation and no
+// per-row predication -- and issues the loads of all R rows (J chunks each)
+// before the first use.  Idle lanes at row tails cost issue slots, not traffic.
+// MODE 0: dictionary values + LDS window; 1: 8-byte values + LDS window;
+// MODE 2: 8-byte values, x gathered from global memory (block without a window);
+// MODE 3: as 0, but code 255 escapes to the 8-byte value (blocks with > 256 distinct values).
+constexpr int32_t kDictEscape = 1 << 16;  // blk_dict_n flag: value code 255 = "read the 8-byte value"
+
+template <int R, int J, int MODE>
+__device__ __forceinline__ void vi_rows(const int64_t (&kb)[R + 1], int lane, const uint16_t *__restrict__ lcol,
+                                        const uint8_t *__restrict__ vidx, const int32_t *__restrict__ col,
+                                        const double *__restrict__ val, const double *xs, const double *ds,
+                                        const double *__restrict__ x, const double *__restrict__ x_halo,
+                                        int32_t n_local, double (&acc)[R]) {
+  int32_t len[R], maxlen = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    len[i] = (int32_t)(kb[i + 1] - kb[i]);
+    maxlen = len[i] > maxlen ? len[i] : maxlen;
+  }
+  for (int32_t base = 0; base < maxlen; base += 64 * J) {  // one pass unless a row has > 64 J entries
+    // Loads are unconditional inside a chunk (lanes past the row end re-read the row's
+    // first entry and are masked at the fma), so each chunk is straight-line code behind
+    // one scalar branch and all loads of the R rows are in flight together.
+    int32_t c[R][J], iv[R][J];
+    uint32_t koff[R][J];
+    double v[R][J];
+    bool ok[R][J];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        ok[i][j] = false;
+        c[i][j] = 0;
+        iv[i][j] = 0;
+        v[i][j] = 0.0;
+        if (base + 64 * j < len[i]) {  // wave-uniform
+          const int32_t o = base + 64 * j + lane;
+          ok[i][j] = o < len[i];
+          // 32-bit offset from the wave-uniform start of the batch (a batch is far below 2^31 entries)
+          const uint32_t k = (uint32_t)(kb[i] - kb[0]) + (uint32_t)(ok[i][j] ? o : 0);
+          if (MODE == 2) c[i][j] = (col + kb[0])[k];
+          else c[i][j] = (lcol + kb[0])[k];
+          if (MODE == 0 || MODE == 3) iv[i][j] = (vidx + kb[0])[k];
+          else v[i][j] = (val + kb[0])[k];
+          if (MODE == 3) koff[i][j] = k;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      double xv[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        xv[j] = 0.0;
+        if (base + 64 * j < len[i]) {  // wave-uniform
+          if (MODE == 2) xv[j] = (c[i][j] < n_local) ? x[c[i][j]] : x_halo[c[i][j] - n_local];
+          else xv[j] = xs[c[i][j]];
+          if (MODE == 0) v[i][j] = ds[iv[i][j]];
+          if (MODE == 3) {
+            v[i][j] = ds[iv[i][j] & 0xff];  // slot 255 is padding; replaced below
+            if (iv[i][j] == 255) v[i][j] = (val + kb[0])[koff[i][j]];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (base + 64 * j < len[i]) {  // wave-uniform
+          if (ok[i][j]) acc[i] = fma(v[i][j], xv[j], acc[i]);
+        }
+    }
+  }
+}
+
+template <int R, int J, int EPI>
+__global__ __launch_bounds__(kBlock) void spmv_window_vi_kernel(
+    int64_t nrows, int32_t RB, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+    const uint16_t *__restrict__ lcol, const double *__restrict__ val,
+    const int32_t *__restrict__ blk_seg_begin, const int32_t *__restrict__ blk_W,
+    const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
+    const double *__restrict__ x, const double *__restrict__ x_halo, int32_t n_local,
+    double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2,
+    const uint8_t *__restrict__ vidx, const int32_t *__restrict__ blk_dict_off,
+    const int32_t *__restrict__ blk_dict_n, const double *__restrict__ dict, int32_t dict_lds_off) {
+  extern __shared__ double xs[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t b = blockIdx.x;
+  const int32_t W = blk_W[b];
+  const double *ds = xs + dict_lds_off;
+  int mode = 2;  // block-uniform
+  if (W >= 0) {
+    const int32_t nd = blk_dict_n[b];
+    mode = nd < 0 ? 1 : ((nd & kDictEscape) ? 3 : 0);
+    const int32_t ndv = nd & 0xffff;
+    if (nd >= 0 && (int)threadIdx.x < ndv) xs[dict_lds_off + threadIdx.x] = dict[blk_dict_off[b] + threadIdx.x];
+    if (mode == 3 && threadIdx.x == 255) xs[dict_lds_off + 255] = 0.0;
+    const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
+    for (int32_t s = s0 + wave; s < s1; s += 4) {
+      const int32_t c0 = seg_col[s], o0 = seg_off[s];
+      const int32_t len = ((s + 1 < s1) ? seg_off[s + 1] : W) - o0;
+      for (int32_t i = lane; i < len; i += 64) {
+        const int32_t c = c0 + i;
+        xs[o0 + i] = (c < n_local) ? x[c] : x_halo[c - n_local];
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t row_begin = b * RB;
+  const int64_t row_end = (row_begin + RB < nrows) ? row_begin + RB : nrows;
+  for (int64_t r0 = row_begin + (int64_t)wave * R; r0 < row_end; r0 += 4 * R) {
+    int64_t kb[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) kb[i] = rp[r0 + i < row_end ? r0 + i : row_end];  // wave-uniform
+    double acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.0;
+    if (mode == 3) vi_rows<R, J, 3>(kb, lane, lcol, vidx, col, val, xs, ds, x, x_halo, n_local, acc);
+    else if (mode == 0) vi_rows<R, J, 0>(kb, lane, lcol, vidx, col, val, xs, ds, x, x_halo, n_local, acc);
+    else if (mode == 1) vi_rows<R, J, 1>(kb, lane, lcol, vidx, col, val, xs, ds, x, x_halo, n_local, acc);
+    else vi_rows<R, J, 2>(kb, lane, lcol, vidx, col, val, xs, ds, x, x_halo, n_local, acc);
+    // rows past row_end have no entries (acc = 0) and are not written
+    static_assert(R == 2 || R == 4, "row batches of 2 or 4");
+    double s;
+    int64_t r;
+    bool writer;
+    if (R == 4) {
+      s = reduce_rows4(acc[0], acc[1], acc[R - 2], acc[R - 1]);
+      const int q = lane >> 4;                         // 16-lane row: holds row {0, 2, 1, 3}[q]
+      r = r0 + (((q & 1) << 1) | (q >> 1));
+      writer = (lane & 15) == 0;
+    } else {
+      s = reduce_rows2(acc[0], acc[1]);
+      r = r0 + (lane >> 5);
+      writer = (lane & 31) == 0;
+    }
+    if (writer && r < row_end) {
+      if (EPI == 0)
+        y[r] = s;
+      else if (EPI == 1)
+        y[r] = fma(alpha, s, y[r]);
+      else if (EPI == 2)
+        y[r] = d[r] * s;
+      else {
+        y[r] = s;
+        y2[r] = d[r] * s;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// The same LDS-window scheme for short-row matrices (canonical L = 8, 16 or 32:
+// Q1 stencils, pressure mass, multigrid level operators).  An L-lane group plays
+// the role of the wave: it owns a batch of R consecutive rows of the block and
+// streams their contiguous entries L*U at a time; the un-rotation and the tree
+// stay inside the group (width-L shuffles), so the result is again the canonical
+// one bit for bit.  Row blocks are larger (RB scales with 64/L) so that a window
+// is amortised over about as many entries as in the long-row kernel.
+template <int L, int R, int U, int EPI, int TAG = 0>
+__global__ __launch_bounds__(kBlock) void spmv_window_group_kernel(
+    int64_t nrows, int32_t RB, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+    const uint16_t *__restrict__ lcol, const double *__restrict__ val,
+    const int32_t *__restrict__ blk_seg_begin, const int32_t *__restrict__ blk_W,
+    const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
+    const double *__restrict__ x, const double *__restrict__ x_halo, int32_t n_local,
+    double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2) {
+  extern __shared__ double xs[];
+  constexpr int G = kBlock / L;  // groups per workgroup
+  const int lane = threadIdx.x % L;
+  const int grp = threadIdx.x / L;
+  const int wlane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t b = blockIdx.x;
+  const int32_t W = blk_W[b];
+  if (W >= 0) {
+    const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
+    for (int32_t s = s0 + wave; s < s1; s += 4) {
+      const int32_t c0 = seg_col[s], o0 = seg_off[s];
+      const int32_t len = ((s + 1 < s1) ? seg_off[s + 1] : W) - o0;
+      for (int32_t i = wlane; i < len; i += 64) {
+        const int32_t c = c0 + i;
+        xs[o0 + i] = (c < n_local) ? x[c] : x_halo[c - n_local];
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t row_begin = b * RB;
+  const int64_t row_end = (row_begin + RB < nrows) ? row_begin + RB : nrows;
+  for (int64_t r0 = row_begin + (int64_t)grp * R; r0 < row_end; r0 += G * R) {
+    int64_t kb[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) kb[i] = rp[r0 + i < row_end ? r0 + i : row_end];  // group-uniform
+    const int64_t k_begin = kb[0];
+    const int32_t n_batch = (int32_t)(kb[R] - k_begin);
+    int32_t rel[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) rel[i] = (int32_t)(kb[i] - k_begin);
+    double acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.0;
+    const double *vb = val + k_begin;
+    const uint16_t *cl = lcol + k_begin;
+    const int32_t *cg = col + k_begin;
+    for (int32_t base = 0; base < n_batch; base += L * U) {
+      int32_t c[U];
+      double v[U], xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t o = base + L * u + lane;
+        if (o < n_batch) {
+          c[u] = (W >= 0) ? (int32_t)cl[o] : cg[o];
+          v[u] = vb[o];
+        } else {
+          c[u] = -1;
+          v[u] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xv[u] = 0.0;
+        if (c[u] >= 0) xv[u] = (W >= 0) ? xs[c[u]] : ((c[u] < n_local) ? x[c[u]] : x_halo[c[u] - n_local]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t o = base + L * u + lane;
+        if (c[u] >= 0) {
+#pragma unroll
+          for (int i = 0; i < R; ++i)
+            if (o >= rel[i] && o < rel[i + 1]) acc[i] = fma(v[u], xv[u], acc[i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      if (r < row_end) {  // group-uniform
+        const int dsh = rel[i] & (L - 1);
+        double s = __shfl(acc[i], (lane + dsh) & (L - 1), L);
+        s = group_reduce<L>(s);
         if (lane == 0) {
           if (EPI == 0)
             y[r] = s;

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "alfd_get_history", "alfd_spmv", "alfd_dot", "alfd_matrix_lanes", "alfd_bench_spmv",
     "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan", "alfd_local_group_create",
     "alfd_local_group_destroy", "alfd_comm_init_local", "alfd_set_aggregates",
-    "alfd_set_aggregate_partition",
+    "alfd_set_aggregate_partition", "alfd_get_matrix_info", "alfd_bench_spmv_format",
 ]
 
 
@@ -90,6 +90,8 @@ def load_library():
         "alfd_comm_init_local": (C.c_int, [vp, vp, C.c_int]),
         "alfd_set_aggregates": (C.c_int, [vp, C.c_int, i64, vp, vp, i64]),
         "alfd_set_aggregate_partition": (C.c_int, [vp, C.c_int, vp]),
+        "alfd_get_matrix_info": (C.c_int, [vp, C.c_int, C.POINTER(_abi.MatrixInfo)]),
+        "alfd_bench_spmv_format": (C.c_int, [vp, C.c_int, i32, C.c_int, C.POINTER(dbl), C.POINTER(dbl)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -262,6 +264,18 @@ class Context:
         ms, nbytes = C.c_double(), C.c_double()
         self._ck(self._lib.alfd_bench_spmv(self._h, slot, reps, C.byref(ms), C.byref(nbytes)))
         return ms.value, nbytes.value
+
+    def bench_spmv_format(self, slot, reps=20, value_index=True):
+        """(ms per launch, bytes streamed by format) with the value-indexed kernel on or off."""
+        ms, nbytes = C.c_double(), C.c_double()
+        self._ck(self._lib.alfd_bench_spmv_format(self._h, slot, reps, int(value_index), C.byref(ms),
+                                                  C.byref(nbytes)))
+        return ms.value, nbytes.value
+
+    def matrix_info(self, slot):
+        info = _abi.MatrixInfo()
+        self._ck(self._lib.alfd_get_matrix_info(self._h, slot, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
 
     def enable_timing(self, on=True):
         self._ck(self._lib.alfd_enable_timing(self._h, int(on)))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 4
+#define ALFD_ABI_VERSION 5
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -293,6 +293,23 @@ int alfd_matrix_lanes(alfd_ctx_t ctx, int slot, int32_t *lanes);
  * the library's stream, plus the algorithmic bytes of one launch. */
 int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launch,
                     double *algorithmic_bytes);
+/* Device storage format chosen for a matrix slot at upload:
+ * lanes per row, LDS-window blocks, and -- for matrices whose row blocks repeat
+ * <= 256 distinct entry values, as finite-element matrices on the reference's
+ * uniformly refined hyper_cube grids do (stokes_immersed_boundary.cc:355-372) --
+ * dictionary-coded values.  streamed_bytes is what one SpMV launch of the kernel
+ * in use moves by format; algorithmic_bytes is the plain-CSR figure of SURVEY 8(d). */
+typedef struct alfd_matrix_info {
+  int32_t lanes, windowed, value_indexed, reserved;
+  int64_t nnz, window_blocks, window_fallback_blocks;
+  int64_t value_indexed_blocks, value_indexed_nnz, dictionary_entries, value_escapes;
+  double algorithmic_bytes, streamed_bytes;
+} alfd_matrix_info;
+int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out);
+/* alfd_bench_spmv with the value-indexed kernel switched on (1) or off (0: the same
+ * matrix through the 10 B/nnz window kernel); streamed_bytes as in alfd_matrix_info. */
+int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value_index,
+                           double *ms_per_launch, double *streamed_bytes);
 /* Kernel-class timing of the last solve, accumulated with HIP events when
  * alfd_enable_timing(ctx, 1) was called before: class ids in alfd_timing_class. */
 enum alfd_timing_class {

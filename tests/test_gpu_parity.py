@@ -71,10 +71,48 @@ def test_spmv_every_kernel_family_bitwise(built):
     big = problems.generate(dim=3, degree=2, ncomp=3, n_cells=20, stokes=False, grad_div=True,
                             gamma_grad_div=10.0, radius=0.1, immersed_refine=0)
     mats["windowed"] = big.mats["A"]       # 206763 rows >= 96*2048 -> LDS-windowed kernel
+    # value-indexed forms of the same matrix: a block dictionary (as uploaded), escape-coded blocks
+    # (5% of the entries made unique) and raw blocks (40% unique); fully random values -> no dictionary
+    expect_format = {"windowed": "dict"}
+    for name, share in (("win_escape", 0.05), ("win_rawblocks", 0.4), ("win_novi", 1.0)):
+        a = big.mats["A"]
+        v = np.array(a.val, copy=True)
+        pick = rng.random(v.size) < share
+        if name == "win_rawblocks":                 # only the first 30% of the rows: those blocks go raw
+            pick[int(a.row_ptr[int(0.3 * a.nrows)]):] = False
+        v[pick] = rng.uniform(-1, 1, int(pick.sum()))
+        mats[name] = problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), v)
+        expect_format[name] = {"win_escape": "escape", "win_rawblocks": "raw", "win_novi": "none"}[name]
+    # short-row window kernel (L-lane groups): L = 32 (27-point), 16 (2-D Q2), 8 (9-point), and a
+    # ragged banded matrix with empty rows plus far-away columns (blocks that fall back to global x)
+    mats["win32"] = problems.generate(dim=3, degree=1, ncomp=1, n_cells=74, radius=0.1).mats["A"]
+    mats["win16"] = problems.generate(dim=2, degree=2, ncomp=1, n_cells=365, radius=0.1).mats["A"]
+    mats["win8"] = problems.generate(dim=2, degree=1, ncomp=1, n_cells=724, radius=0.1).mats["A"]
+    n = 540000
+    cnt = rng.integers(0, 21, n)
+    rows = np.repeat(np.arange(n), cnt)
+    cols = np.clip(rows + rng.integers(-400, 401, rows.size), 0, n - 1)
+    far = rng.integers(0, rows.size, 200)
+    cols[far] = rng.integers(0, n, 200)
+    a = sp.csr_matrix((rng.uniform(-1, 1, rows.size), (rows, cols)), shape=(n, n))
+    a.sum_duplicates()
+    mats["win_ragged"] = problems.Csr.from_scipy(a)
     ctx = solver.Context(0)
     try:
         for name, m in mats.items():
             ctx.set_matrix(_abi.A, m)
+            info = ctx.matrix_info(_abi.A)
+            fmt = expect_format.get(name)
+            if fmt == "dict":
+                assert info["value_indexed"] and info["value_escapes"] == 0 and info["value_indexed_nnz"] == m.nnz
+            elif fmt == "escape":
+                assert info["value_indexed"] and 0 < info["value_escapes"] < m.nnz // 8
+            elif fmt == "raw":
+                assert info["value_indexed"] and 0 < info["value_indexed_blocks"] < info["window_blocks"]
+            elif fmt == "none":
+                assert info["windowed"] and not info["value_indexed"]
+            if name.startswith("win") and name != "win_ragged":
+                assert info["windowed"], name
             x = rng.uniform(-1, 1, m.ncols)
             y0 = rng.uniform(-1, 1, m.nrows)
             for mode in (0, 1):
@@ -258,7 +296,14 @@ def test_error_behaviour(ctxs):
 def test_no_device_memory_growth_across_reupload_and_setup(built):
     """Re-uploading every slot and repeating alfd_setup (which rebuilds the multigrid
     hierarchy) must release the previous device arrays."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def used_mb():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return (total.value - free.value) / 1e6
+
     pb = problems.stokes3d_sphere(16, 1)
     cfg = _abi.default_config(_abi.AL_STOKES)
     cfg.inner.max_steps = 2000
@@ -270,8 +315,7 @@ def test_no_device_memory_growth_across_reupload_and_setup(built):
     for _ in range(5):
         solver.upload_problem(ctx, pb, cfg, aggs)
         ctx.solve(ctx.augment_rhs(cases.rhs_of(pb)))
-        free, total = torch.cuda.mem_get_info(0)
-        used.append((total - free) / 1e6)
+        used.append(used_mb())
     ctx.close()
     assert used[-1] - used[1] < 16.0, used          # MB
 
