@@ -30,6 +30,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "alfd/alfd.h"
@@ -218,6 +219,7 @@ struct alfd_ctx {
   int spmv_group_R = 4, spmv_group_U = 4;  // batch shape of the short-row window kernel
   bool vi_off = false;                      // alfd_bench_spmv_format: time the plain 10 B/nnz kernel on a value-indexed matrix
   int vi_rows_R = 4, vi_rows_J = 2;         // row-batched VI kernel shape (ALFD_SPMV_VI_R=0: stream-ordered VI kernel)
+  int win_RB_vi = 48;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
   int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
@@ -1281,14 +1283,35 @@ static int short_row_block(const alfd_ctx *ctx, int L) {
 static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col, const double *val,
                         bool slot_is_user) {
   // short rows: larger row blocks, so a window serves about as many entries as for L = 64
-  const int RB = short_row_block(ctx, m.L);
+  int RB = short_row_block(ctx, m.L);
+  const bool vi_candidate = ctx->win_vi && m.L == 64 && slot_is_user;
+  if (vi_candidate && ctx->win_RB_vi > 0 && ctx->win_RB_vi != RB) {
+    // The value-indexed kernel is latency-bound, not HBM-bound, and prefers smaller row blocks
+    // (smaller windows, more resident workgroups).  Sample a few blocks: if their values
+    // look dictionary-codable, build the window format with the smaller block.
+    const int64_t nb96 = (m.nrows + RB - 1) / RB;
+    int good = 0, seen = 0;
+    for (int64_t q = 0; q < 32 && q < nb96; ++q) {
+      const int64_t b = nb96 * q / std::min<int64_t>(32, nb96);
+      const int64_t k0 = rp[b * RB], k1 = rp[std::min<int64_t>((b + 1) * RB, m.nrows)];
+      std::unordered_set<uint64_t> u;
+      for (int64_t k = k0; k < k1 && u.size() <= 1024; ++k) {
+        uint64_t bits;
+        std::memcpy(&bits, &val[k], 8);
+        u.insert(bits);
+      }
+      ++seen;
+      good += u.size() <= 1024;
+    }
+    if (good * 4 >= seen * 3) RB = ctx->win_RB_vi;
+  }
   const int maxW = ctx->win_maxW, GAP = ctx->win_gap;
   const int64_t nb = (m.nrows + RB - 1) / RB;
   if (nb == 0 || nb > 2147483000LL) return ALFD_OK;
   std::vector<uint16_t> lcol(m.nnz);
   std::vector<int32_t> blkW(nb), blk_nseg(nb);
   // value dictionaries: long-row fine operators only (level matrices are Galerkin products)
-  const bool want_vi = ctx->win_vi && m.L == 64 && slot_is_user;
+  const bool want_vi = vi_candidate;
   std::vector<uint8_t> vidx(want_vi ? m.nnz : 0);
   std::vector<int32_t> blk_dn(nb, -1);
   std::vector<std::vector<double>> t_dict(want_vi ? nb : 0);
@@ -2344,6 +2367,7 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW")) ctx->win_enable = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB")) ctx->win_RB = std::max(4, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
+  if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB_VI")) ctx->win_RB_vi = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_R")) ctx->vi_rows_R = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_J")) ctx->vi_rows_J = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VALUE_INDEX")) ctx->win_vi = std::atoi(e);

@@ -414,22 +414,19 @@ __device__ __forceinline__ void vi_rows(const int64_t (&kb)[R + 1], int lane, co
     maxlen = len[i] > maxlen ? len[i] : maxlen;
   }
   for (int32_t base = 0; base < maxlen; base += 64 * J) {  // one pass unless a row has > 64 J entries
-    // Loads are unconditional inside a chunk (lanes past the row end re-read the row's
-    // first entry and are masked at the fma), so each chunk is straight-line code behind
-    // one scalar branch and all loads of the R rows are in flight together.
+    // One wave-uniform guard per row and pass; inside it the J chunks are straight-line code:
+    // lanes past the row end re-read the row's first entry (a cache hit) and are masked at
+    // the fma.  Everything loaded under a guard is only used under the same guard, so the
+    // arrays need no defaults, and all loads of the R rows are in flight before the first use.
     int32_t c[R][J], iv[R][J];
     uint32_t koff[R][J];
     double v[R][J];
     bool ok[R][J];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
+      if (base < len[i]) {  // wave-uniform
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        ok[i][j] = false;
-        c[i][j] = 0;
-        iv[i][j] = 0;
-        v[i][j] = 0.0;
-        if (base + 64 * j < len[i]) {  // wave-uniform
+        for (int j = 0; j < J; ++j) {
           const int32_t o = base + 64 * j + lane;
           ok[i][j] = o < len[i];
           // 32-bit offset from the wave-uniform start of the batch (a batch is far below 2^31 entries)
@@ -444,25 +441,27 @@ __device__ __forceinline__ void vi_rows(const int64_t (&kb)[R + 1], int lane, co
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      double xv[J];
+      if (base < len[i]) {  // wave-uniform
+        double xv[J];
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        xv[j] = 0.0;
-        if (base + 64 * j < len[i]) {  // wave-uniform
+        for (int j = 0; j < J; ++j) {
           if (MODE == 2) xv[j] = (c[i][j] < n_local) ? x[c[i][j]] : x_halo[c[i][j] - n_local];
           else xv[j] = xs[c[i][j]];
-          if (MODE == 0) v[i][j] = ds[iv[i][j]];
-          if (MODE == 3) {
-            v[i][j] = ds[iv[i][j] & 0xff];  // slot 255 is padding; replaced below
-            if (iv[i][j] == 255) v[i][j] = (val + kb[0])[koff[i][j]];
-          }
+          if (MODE == 0 || MODE == 3) v[i][j] = ds[iv[i][j]];  // MODE 3: slot 255 is padding, replaced below
         }
-      }
+        // keep the gathers of all J chunks ahead of the masked fmas (the compiler would
+        // otherwise sink each ds_read into its exec-masked block and wait on it there)
 #pragma unroll
-      for (int j = 0; j < J; ++j)
-        if (base + 64 * j < len[i]) {  // wave-uniform
-          if (ok[i][j]) acc[i] = fma(v[i][j], xv[j], acc[i]);
+        for (int j = 0; j < J; ++j) asm volatile("" : "+v"(xv[j]), "+v"(v[i][j]));
+        if (MODE == 3) {
+#pragma unroll
+          for (int j = 0; j < J; ++j)
+            if (iv[i][j] == 255) v[i][j] = (val + kb[0])[koff[i][j]];
         }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          if (ok[i][j]) acc[i] = fma(v[i][j], xv[j], acc[i]);
+      }
     }
   }
 }
