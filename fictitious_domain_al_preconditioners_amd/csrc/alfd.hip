@@ -615,8 +615,12 @@ static int dot_async(alfd_ctx *ctx, int64_t npad, const double *x, const double 
 }
 
 static int read_scalars(alfd_ctx *ctx, int first, int count) {
-  HIPC(hipMemcpyAsync(ctx->sc_host + first, ctx->sc + first, count * sizeof(double), hipMemcpyDeviceToHost,
-                      ctx->stream));
+  // The mirror is mapped pinned host memory: a one-workgroup kernel stores the scalars
+  // there directly (a D2H hipMemcpyAsync goes through the runtime's blit kernels, which
+  // cost far more than this launch at one readback per CG iteration).
+  hipLaunchKernelGGL(mirror_scalars_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->sc + first,
+                     ctx->sc_host + first, count);
+  HIPC(hipGetLastError());
   HIPC(hipStreamSynchronize(ctx->stream));
   return ALFD_OK;
 }
@@ -2143,7 +2147,7 @@ static int setup(alfd_ctx *ctx) {
   const int64_t wm = ctx->wmax;
   ctx->pstride = N / kChunk + 1;
   RC(ws_alloc_zero(ctx, &ctx->sc, kNumScalars));
-  HIPC(hipHostMalloc((void **)&ctx->sc_host, kNumScalars * sizeof(double)));
+  HIPC(hipHostMalloc((void **)&ctx->sc_host, kNumScalars * sizeof(double), hipHostMallocMapped));
   RC(ws_alloc_zero(ctx, &ctx->partial, (int64_t)(kMaxBasis + 2) * ctx->pstride));
   RC(ws_alloc_zero(ctx, &ctx->gather, (int64_t)ctx->nranks * (kMaxBasis + 2)));
   RC(ws_alloc_zero(ctx, &ctx->dinv_aug, n0p));

@@ -649,6 +649,12 @@ __global__ __launch_bounds__(kBlock) void spmv_window_group_kernel(
   }
 }
 
+// device scalars -> mapped pinned host mirror (read by the host after a stream sync)
+__global__ void mirror_scalars_kernel(const double *__restrict__ sc, double *__restrict__ host, int count) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) host[i] = sc[i];
+  __threadfence_system();
+}
+
 // --------------------------------------------------------------------------
 // Streaming vector kernels. All vectors are padded to a multiple of kChunk with
 // zeros, so no bounds checks: one workgroup per chunk, thread t owns the pairs
