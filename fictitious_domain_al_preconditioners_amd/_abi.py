@@ -74,7 +74,7 @@ class MatrixInfo(C.Structure):
         ("lanes", C.c_int32), ("windowed", C.c_int32), ("value_indexed", C.c_int32), ("reserved", C.c_int32),
         ("nnz", C.c_int64), ("window_blocks", C.c_int64), ("window_fallback_blocks", C.c_int64),
         ("value_indexed_blocks", C.c_int64), ("value_indexed_nnz", C.c_int64),
-        ("dictionary_entries", C.c_int64), ("value_escapes", C.c_int64),
+        ("dictionary_entries", C.c_int64), ("value_wide_nnz", C.c_int64),
         ("algorithmic_bytes", C.c_double), ("streamed_bytes", C.c_double),
     ]
 

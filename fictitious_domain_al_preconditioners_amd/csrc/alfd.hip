@@ -85,7 +85,11 @@ struct DevCsr {
   uint8_t *vidx = nullptr;
   int32_t *blk_dict_off = nullptr, *blk_dict_n = nullptr;
   double *dict = nullptr;
-  int64_t vi_blocks = 0, vi_nnz = 0, vi_dict_total = 0, vi_escapes = 0;
+  int64_t vi_blocks = 0, vi_nnz = 0, vi_dict_total = 0, vi_wide_nnz = 0;
+  uint16_t *vidw = nullptr;  // 16-bit value codes of the blocks with 257..512 distinct values
+  uint64_t *vib_tab = nullptr;  // class-sorted row batches per block (spmv_window_vib_kernel)
+  int32_t *vib_cnt = nullptr;
+  int32_t vib_stride = 0;
   int32_t *blk_seg_begin = nullptr, *blk_W = nullptr, *seg_col = nullptr, *seg_off = nullptr;
   // bytes the kernel in use moves per launch (format bytes, x read once)
   double streamed_bytes(bool use_vi) const {
@@ -93,8 +97,8 @@ struct DevCsr {
     if (!win) return (double)nnz * 12.0 + vec;
     const double meta = (double)win_nblocks * 8.0 + (double)win_nseg * 8.0;
     if (!(vi && use_vi)) return (double)nnz * 10.0 + vec + meta;
-    return (double)vi_nnz * 3.0 + (double)vi_escapes * 11.0 + (double)(nnz - vi_nnz - vi_escapes) * 10.0 + vec + meta + (double)vi_dict_total * 8.0 +
-           (double)win_nblocks * 8.0;
+    return (double)(vi_nnz - vi_wide_nnz) * 3.0 + (double)vi_wide_nnz * 4.0 + (double)(nnz - vi_nnz) * 10.0 + vec + meta + (double)vi_dict_total * 8.0 +
+           (double)win_nblocks * (8.0 + (vib_tab ? 32.0 * vib_stride + 4.0 : 0.0));
   }
   double algorithmic_bytes() const {
     // nnz*(8+4) + (nrows+1)*8 + nrows*8 + ncols*8  (x read once)
@@ -219,7 +223,8 @@ struct alfd_ctx {
   int spmv_group_R = 4, spmv_group_U = 4;  // batch shape of the short-row window kernel
   bool vi_off = false;                      // alfd_bench_spmv_format: time the plain 10 B/nnz kernel on a value-indexed matrix
   int vi_rows_R = 4, vi_rows_J = 2;         // row-batched VI kernel shape (ALFD_SPMV_VI_R=0: stream-ordered VI kernel)
-  int win_RB_vi = 48;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
+  int vi_batched = 1;                       // class-batched VI kernel (ALFD_SPMV_VI_BATCHED=0: in-order batches)
+  int win_RB_vi = 96;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
   int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
@@ -435,19 +440,32 @@ static bool launch_stream_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, do
 template <int R, int U>
 static void launch_window(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
                           const double *d, double *y2) {
-  const size_t lds = (size_t)(m.win_maxW + (m.vi && !ctx->vi_off ? 256 : 0)) * sizeof(double);
+  const size_t lds = (size_t)(m.win_maxW + (m.vi && !ctx->vi_off ? kDictMaxEntries : 0)) * sizeof(double);
 #define ALFD_WIN(EPI, TAG)                                                                              \
   hipLaunchKernelGGL((spmv_window_kernel<R, U, EPI, TAG>), dim3((unsigned)m.win_nblocks), dim3(kBlock), \
                      lds, ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin,   \
                      m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->win_xcd)
   const bool vi = m.vi && !ctx->vi_off;
+  if (vi && ctx->vi_batched && m.vib_tab) {
+#define ALFD_VIB(EPI)                                                                                         \
+  hipLaunchKernelGGL((spmv_window_vib_kernel<EPI>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds,        \
+                     ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin, m.blk_W,    \
+                     m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, m.vidx, m.vidw, \
+                     m.blk_dict_off, m.blk_dict_n, m.dict, m.win_maxW, m.vib_tab, m.vib_cnt, m.vib_stride)
+    if (epi == 0) ALFD_VIB(0);
+    else if (epi == 1) ALFD_VIB(1);
+    else if (epi == 2) ALFD_VIB(2);
+    else ALFD_VIB(3);
+#undef ALFD_VIB
+    return;
+  }
   if (vi && ctx->vi_rows_R > 0) {
     const int RR = ctx->vi_rows_R, JJ = ctx->vi_rows_J;
 #define ALFD_VI(RV, JV, EPI)                                                                                  \
   hipLaunchKernelGGL((spmv_window_vi_kernel<RV, JV, EPI>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds,  \
                      ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin, m.blk_W,     \
-                     m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, m.vidx, m.blk_dict_off, \
-                     m.blk_dict_n, m.dict, m.win_maxW)
+                     m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, m.vidx, m.vidw, \
+                     m.blk_dict_off, m.blk_dict_n, m.dict, m.win_maxW)
 #define ALFD_VI_E(RV, JV)              \
   if (RR == RV && JJ == JV) {          \
     if (epi == 0) ALFD_VI(RV, JV, 0);  \
@@ -1319,7 +1337,8 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
   std::vector<uint8_t> vidx(want_vi ? m.nnz : 0);
   std::vector<int32_t> blk_dn(nb, -1);
   std::vector<std::vector<double>> t_dict(want_vi ? nb : 0);
-  std::vector<int64_t> t_escapes(64, 0);
+  std::vector<uint16_t> vidw(want_vi ? m.nnz : 0);  // 16-bit codes (kept only if some block needs them)
+  std::vector<int64_t> t_wide(64, 0);
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::vector<int32_t>> t_seg_col(T), t_seg_off(T);
   std::vector<std::thread> th;
@@ -1378,64 +1397,41 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
         blk_nseg[b] = nseg;
         for (int64_t k = k0; k < k1; ++k) lcol[k] = (uint16_t)pos[col[k] - clo];
         if (want_vi) {
-          // open-addressing table over the 64-bit patterns, with counts.  Up to 256 distinct
-          // values: plain dictionary.  Up to kMaxDistinct: the 255 most frequent values get
-          // codes 0..254 and code 255 is an escape (the kernel reads the 8-byte value), as
-          // long as escapes stay below 1/8 of the block's entries.  Beyond that: raw block.
-          constexpr int kTab = 4096, kMaxDistinct = 1024;
+          // open-addressing table over the 64-bit patterns.  Up to 256 distinct values:
+          // 8-bit codes; up to kDictMaxEntries: 16-bit codes; beyond that: raw block.
+          constexpr int kTab = 2048;
           std::vector<uint64_t> keys(kTab);
           std::vector<int16_t> ids(kTab, (int16_t)-1);
-          std::vector<double> all_vals;
-          std::vector<int32_t> counts;
-          std::vector<int16_t> first_id(k1 - k0);
+          std::vector<double> &dv = t_dict[b];
           bool ok = true;
           for (int64_t k = k0; k < k1 && ok; ++k) {
             uint64_t bits;
             std::memcpy(&bits, &val[k], 8);
-            uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 52);
+            uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 53);
             for (;;) {
               if (ids[h] < 0) {
-                if ((int)all_vals.size() == kMaxDistinct) {
+                if ((int)dv.size() == kDictMaxEntries) {
                   ok = false;
                   break;
                 }
                 keys[h] = bits;
-                ids[h] = (int16_t)all_vals.size();
-                all_vals.push_back(val[k]);
-                counts.push_back(0);
+                ids[h] = (int16_t)dv.size();
+                dv.push_back(val[k]);
                 break;
               }
               if (keys[h] == bits) break;
               h = (h + 1) & (kTab - 1);
             }
-            if (ok) {
-              first_id[k - k0] = ids[h];
-              ++counts[ids[h]];
-            }
+            if (ok) vidw[k] = (uint16_t)ids[h];
           }
-          std::vector<double> &dv = t_dict[b];
-          if (ok && all_vals.size() <= 256) {
-            dv = all_vals;
-            for (int64_t k = k0; k < k1; ++k) vidx[k] = (uint8_t)first_id[k - k0];
+          if (!ok) {
+            dv.clear();
+          } else if (dv.size() <= 256) {
+            for (int64_t k = k0; k < k1; ++k) vidx[k] = (uint8_t)vidw[k];
             blk_dn[b] = (int32_t)dv.size();
-          } else if (ok) {
-            std::vector<int32_t> order(all_vals.size());
-            for (size_t q = 0; q < order.size(); ++q) order[q] = (int32_t)q;
-            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t c) { return counts[a] > counts[c]; });
-            std::vector<int16_t> code(all_vals.size(), (int16_t)255);
-            int64_t covered = 0;
-            for (int q = 0; q < 255; ++q) {
-              code[order[q]] = (int16_t)q;
-              covered += counts[order[q]];
-              dv.push_back(all_vals[order[q]]);
-            }
-            if ((k1 - k0 - covered) * 8 <= (k1 - k0)) {
-              for (int64_t k = k0; k < k1; ++k) vidx[k] = (uint8_t)code[first_id[k - k0]];
-              blk_dn[b] = 255 | kDictEscape;
-              t_escapes[t] += k1 - k0 - covered;
-            } else {
-              dv.clear();
-            }
+          } else {
+            blk_dn[b] = (int32_t)dv.size() | kDictWide;
+            t_wide[t] += k1 - k0;
           }
         }
       }
@@ -1482,18 +1478,63 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
       ++nvb;
       nvn += rp[std::min<int64_t>((b + 1) * RB, m.nrows)] - rp[b * RB];
     }
-    for (int64_t e : t_escapes) m.vi_escapes += e;
-    nvn -= m.vi_escapes;
+    for (int64_t e : t_wide) m.vi_wide_nnz += e;
     if (nvb * 2 > nb && dict.size() < 2000000000ull) {  // worthwhile: most blocks are dictionary-coded
       RC(csr_alloc(ctx, m, &m.vidx, m.nnz));
       RC(csr_alloc(ctx, m, &m.blk_dict_off, nb));
       RC(csr_alloc(ctx, m, &m.blk_dict_n, nb));
       RC(csr_alloc(ctx, m, &m.dict, (int64_t)dict.size()));
       HIPC(hipMemcpyAsync(m.vidx, vidx.data(), m.nnz, hipMemcpyHostToDevice, ctx->stream));
+      if (m.vi_wide_nnz > 0) {
+        RC(csr_alloc(ctx, m, &m.vidw, m.nnz));
+        HIPC(hipMemcpyAsync(m.vidw, vidw.data(), m.nnz * 2, hipMemcpyHostToDevice, ctx->stream));
+      }
       HIPC(hipMemcpyAsync(m.blk_dict_off, doff.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
       HIPC(hipMemcpyAsync(m.blk_dict_n, blk_dn.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
       HIPC(hipMemcpyAsync(m.dict, dict.data(), dict.size() * 8, hipMemcpyHostToDevice, ctx->stream));
       HIPC(hipStreamSynchronize(ctx->stream));
+      int64_t longest = 0;
+      for (int64_t r = 0; r < m.nrows; ++r) longest = std::max(longest, rp[r + 1] - rp[r]);
+      if (RB <= 250 && longest <= 65535) {
+        // class-sorted batches of 4 rows per block
+        const int stride = (RB + 3) / 4 + kVibMaxClass + 2;
+        std::vector<uint64_t> tab((size_t)nb * stride * 4, 0);
+        std::vector<int32_t> cnt(nb, 0);
+        std::vector<std::thread> th2;
+        for (int t = 0; t < T; ++t)
+          th2.emplace_back([&, t]() {
+            std::vector<int> ids[kVibMaxClass + 2];
+            for (int64_t b = nb * t / T; b < nb * (t + 1) / T; ++b) {
+              const int64_t r0 = b * RB, r1 = std::min<int64_t>(r0 + RB, m.nrows);
+              for (auto &v : ids) v.clear();
+              for (int64_t r = r0; r < r1; ++r) {
+                const int64_t len = rp[r + 1] - rp[r];
+                const int64_t cls = (len + 63) / 64;
+                ids[cls > kVibMaxClass ? kVibMaxClass + 1 : cls].push_back((int)(r - r0));
+              }
+              int nbt = 0;
+              for (int cls = 0; cls <= kVibMaxClass + 1; ++cls)
+                for (size_t q = 0; q < ids[cls].size(); q += 4) {
+                  uint64_t *dst = &tab[((size_t)b * stride + nbt++) * 4];
+                  for (int i = 0; i < 4; ++i) {
+                    const bool real = q + i < ids[cls].size();
+                    const int id = ids[cls][real ? q + i : q];  // filler: repeat the batch's first row
+                    const uint64_t ks = (uint64_t)(rp[r0 + id] - rp[r0]);
+                    const uint64_t len = (uint64_t)(rp[r0 + id + 1] - rp[r0 + id]);
+                    dst[i] = ks | (len << 32) | ((uint64_t)(real ? id : 0xff) << 48) | ((uint64_t)cls << 56);
+                  }
+                }
+              cnt[b] = nbt;
+            }
+          });
+        for (auto &x : th2) x.join();
+        RC(csr_alloc(ctx, m, &m.vib_tab, (int64_t)tab.size()));
+        RC(csr_alloc(ctx, m, &m.vib_cnt, nb));
+        HIPC(hipMemcpyAsync(m.vib_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipMemcpyAsync(m.vib_cnt, cnt.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+        m.vib_stride = stride;
+      }
       m.vi = true;
       m.vi_blocks = nvb;
       m.vi_nnz = nvn;
@@ -2371,6 +2412,7 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW")) ctx->win_enable = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB")) ctx->win_RB = std::max(4, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
+  if (const char *e = std::getenv("ALFD_SPMV_VI_BATCHED")) ctx->vi_batched = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB_VI")) ctx->win_RB_vi = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_R")) ctx->vi_rows_R = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_J")) ctx->vi_rows_J = std::atoi(e);
@@ -2807,7 +2849,7 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   out->value_indexed_blocks = m.vi_blocks;
   out->value_indexed_nnz = m.vi_nnz;
   out->dictionary_entries = m.vi_dict_total;
-  out->value_escapes = m.vi_escapes;
+  out->value_wide_nnz = m.vi_wide_nnz;
   out->algorithmic_bytes = m.algorithmic_bytes();
   out->streamed_bytes = m.streamed_bytes(true);
   return ALFD_OK;

@@ -385,9 +385,8 @@ __global__ __launch_bounds__(kBlock) void spmv_window_kernel(
 // whose entries take <= 256 distinct bit patterns gets a private dictionary (stored once,
 // staged into LDS next to the x window) and an 8-bit code per entry, so the stream is
 // 2 B (window column) + 1 B (value code) = 3 B/nnz instead of 10.  The looked-up double
-// is the stored one bit for bit, so results do not change.  Blocks with somewhat more
-// values keep the 255 most frequent in the dictionary and mark the rest with an escape
-// code; blocks beyond that keep streaming the 8-byte values.
+// is the stored one bit for bit, so results do not change.  Blocks with 257..512 distinct
+// values use 16-bit codes (4 B/nnz); blocks beyond that keep streaming the 8-byte values.
 //
 // Row-batched window kernel for value-indexed matrices.  With 3 B/nnz the stream
 // is no longer HBM-bound but latency-bound, so the kernel is organised to keep
@@ -398,28 +397,28 @@ __global__ __launch_bounds__(kBlock) void spmv_window_kernel(
 // before the first use.  Idle lanes at row tails cost issue slots, not traffic.
 // MODE 0: dictionary values + LDS window; 1: 8-byte values + LDS window;
 // MODE 2: 8-byte values, x gathered from global memory (block without a window);
-// MODE 3: as 0, but code 255 escapes to the 8-byte value (blocks with > 256 distinct values).
-constexpr int32_t kDictEscape = 1 << 16;  // blk_dict_n flag: value code 255 = "read the 8-byte value"
+// MODE 3: as 0 with 16-bit value codes (blocks with 257..512 distinct values).
+constexpr int32_t kDictWide = 1 << 16;    // blk_dict_n flag: 16-bit codes
+constexpr int32_t kDictMaxEntries = 512;  // LDS slots reserved for a block dictionary
 
+// ks[i]: offset of row i's first entry from the block's first entry (the *_b pointers are
+// pre-offset to it); len[i]: its entry count.
 template <int R, int J, int MODE>
-__device__ __forceinline__ void vi_rows(const int64_t (&kb)[R + 1], int lane, const uint16_t *__restrict__ lcol,
-                                        const uint8_t *__restrict__ vidx, const int32_t *__restrict__ col,
-                                        const double *__restrict__ val, const double *xs, const double *ds,
-                                        const double *__restrict__ x, const double *__restrict__ x_halo,
-                                        int32_t n_local, double (&acc)[R]) {
-  int32_t len[R], maxlen = 0;
+__device__ __forceinline__ void vi_rows(const uint32_t (&ks)[R], const int32_t (&len)[R], int lane,
+                                        const uint16_t *__restrict__ lcol_b, const uint8_t *__restrict__ vidx_b,
+                                        const uint16_t *__restrict__ vidw_b,
+                                        const int32_t *__restrict__ col_b, const double *__restrict__ val_b,
+                                        const double *xs, const double *ds, const double *__restrict__ x,
+                                        const double *__restrict__ x_halo, int32_t n_local, double (&acc)[R]) {
+  int32_t maxlen = 0;
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    len[i] = (int32_t)(kb[i + 1] - kb[i]);
-    maxlen = len[i] > maxlen ? len[i] : maxlen;
-  }
+  for (int i = 0; i < R; ++i) maxlen = len[i] > maxlen ? len[i] : maxlen;
   for (int32_t base = 0; base < maxlen; base += 64 * J) {  // one pass unless a row has > 64 J entries
     // One wave-uniform guard per row and pass; inside it the J chunks are straight-line code:
     // lanes past the row end re-read the row's first entry (a cache hit) and are masked at
     // the fma.  Everything loaded under a guard is only used under the same guard, so the
     // arrays need no defaults, and all loads of the R rows are in flight before the first use.
     int32_t c[R][J], iv[R][J];
-    uint32_t koff[R][J];
     double v[R][J];
     bool ok[R][J];
 #pragma unroll
@@ -429,13 +428,12 @@ __device__ __forceinline__ void vi_rows(const int64_t (&kb)[R + 1], int lane, co
         for (int j = 0; j < J; ++j) {
           const int32_t o = base + 64 * j + lane;
           ok[i][j] = o < len[i];
-          // 32-bit offset from the wave-uniform start of the batch (a batch is far below 2^31 entries)
-          const uint32_t k = (uint32_t)(kb[i] - kb[0]) + (uint32_t)(ok[i][j] ? o : 0);
-          if (MODE == 2) c[i][j] = (col + kb[0])[k];
-          else c[i][j] = (lcol + kb[0])[k];
-          if (MODE == 0 || MODE == 3) iv[i][j] = (vidx + kb[0])[k];
-          else v[i][j] = (val + kb[0])[k];
-          if (MODE == 3) koff[i][j] = k;
+          const uint32_t k = ks[i] + (uint32_t)(ok[i][j] ? o : 0);
+          if (MODE == 2) c[i][j] = col_b[k];
+          else c[i][j] = lcol_b[k];
+          if (MODE == 0) iv[i][j] = vidx_b[k];
+          else if (MODE == 3) iv[i][j] = vidw_b[k];
+          else v[i][j] = val_b[k];
         }
       }
     }
@@ -447,23 +445,75 @@ __device__ __forceinline__ void vi_rows(const int64_t (&kb)[R + 1], int lane, co
         for (int j = 0; j < J; ++j) {
           if (MODE == 2) xv[j] = (c[i][j] < n_local) ? x[c[i][j]] : x_halo[c[i][j] - n_local];
           else xv[j] = xs[c[i][j]];
-          if (MODE == 0 || MODE == 3) v[i][j] = ds[iv[i][j]];  // MODE 3: slot 255 is padding, replaced below
+          if (MODE == 0 || MODE == 3) v[i][j] = ds[iv[i][j]];
         }
         // keep the gathers of all J chunks ahead of the masked fmas (the compiler would
         // otherwise sink each ds_read into its exec-masked block and wait on it there)
 #pragma unroll
         for (int j = 0; j < J; ++j) asm volatile("" : "+v"(xv[j]), "+v"(v[i][j]));
-        if (MODE == 3) {
-#pragma unroll
-          for (int j = 0; j < J; ++j)
-            if (iv[i][j] == 255) v[i][j] = (val + kb[0])[koff[i][j]];
-        }
 #pragma unroll
         for (int j = 0; j < J; ++j)
           if (ok[i][j]) acc[i] = fma(v[i][j], xv[j], acc[i]);
       }
     }
   }
+}
+
+template <int J0, int JN, int NCH, int MODE>
+__device__ __forceinline__ void vib_pass(const uint32_t (&ks)[4], const int32_t (&len)[4], int lane,
+                                         const uint16_t *__restrict__ lcol_b,
+                                         const uint8_t *__restrict__ vidx_b, const uint16_t *__restrict__ vidw_b,
+                                         const double *xs, const double *ds, double (&acc)[4]) {
+  // chunks J0 .. J0+JN-1 of every row of the batch; chunk NCH-1 is the only partial one
+  int32_t c[4][JN], iv[4][JN];
+  bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      const int32_t o = 64 * (J0 + j) + lane;
+      uint32_t k = ks[i] + (uint32_t)o;
+      if (J0 + j == NCH - 1) {
+        ok[i] = o < len[i];
+        k = ks[i] + (uint32_t)(ok[i] ? o : 0);
+      }
+      c[i][j] = lcol_b[k];
+      iv[i][j] = MODE == 3 ? (int32_t)vidw_b[k] : (int32_t)vidx_b[k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double xv[JN], v[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      xv[j] = xs[c[i][j]];
+      v[j] = ds[iv[i][j]];
+    }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) asm volatile("" : "+v"(xv[j]), "+v"(v[j]));
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+      if (J0 + j == NCH - 1) {
+        if (ok[i]) acc[i] = fma(v[j], xv[j], acc[i]);
+      } else {
+        acc[i] = fma(v[j], xv[j], acc[i]);
+      }
+    }
+  }
+}
+
+// Batch of 4 rows that all have exactly NCH 64-entry chunks (the last one possibly partial):
+// no guards at all, and only the last chunk of each row carries a lane mask.  At most 3
+// chunks per row are in flight at a time (12 chunk loads, ~56 VGPRs: 8 waves per SIMD).
+// MODE 0 (8-bit codes) or 3 (16-bit codes).
+template <int NCH, int MODE>
+__device__ __forceinline__ void vib_rows(const uint32_t (&ks)[4], const int32_t (&len)[4], int lane,
+                                         const uint16_t *__restrict__ lcol_b,
+                                         const uint8_t *__restrict__ vidx_b, const uint16_t *__restrict__ vidw_b,
+                                         const double *xs, const double *ds, double (&acc)[4]) {
+  constexpr int A = NCH <= 3 ? NCH : (NCH + 1) / 2;
+  vib_pass<0, A, NCH, MODE>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc);
+  if (NCH > A) vib_pass<A, (NCH > A ? NCH - A : 1), NCH, MODE>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc);
 }
 
 template <int R, int J, int EPI>
@@ -474,8 +524,9 @@ __global__ __launch_bounds__(kBlock) void spmv_window_vi_kernel(
     const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
     const double *__restrict__ x, const double *__restrict__ x_halo, int32_t n_local,
     double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2,
-    const uint8_t *__restrict__ vidx, const int32_t *__restrict__ blk_dict_off,
-    const int32_t *__restrict__ blk_dict_n, const double *__restrict__ dict, int32_t dict_lds_off) {
+    const uint8_t *__restrict__ vidx, const uint16_t *__restrict__ vidw,
+    const int32_t *__restrict__ blk_dict_off, const int32_t *__restrict__ blk_dict_n,
+    const double *__restrict__ dict, int32_t dict_lds_off) {
   extern __shared__ double xs[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -485,10 +536,10 @@ __global__ __launch_bounds__(kBlock) void spmv_window_vi_kernel(
   int mode = 2;  // block-uniform
   if (W >= 0) {
     const int32_t nd = blk_dict_n[b];
-    mode = nd < 0 ? 1 : ((nd & kDictEscape) ? 3 : 0);
+    mode = nd < 0 ? 1 : ((nd & kDictWide) ? 3 : 0);
     const int32_t ndv = nd & 0xffff;
-    if (nd >= 0 && (int)threadIdx.x < ndv) xs[dict_lds_off + threadIdx.x] = dict[blk_dict_off[b] + threadIdx.x];
-    if (mode == 3 && threadIdx.x == 255) xs[dict_lds_off + 255] = 0.0;
+    if (nd >= 0)
+      for (int t = threadIdx.x; t < ndv; t += kBlock) xs[dict_lds_off + t] = dict[blk_dict_off[b] + t];
     const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
     for (int32_t s = s0 + wave; s < s1; s += 4) {
       const int32_t c0 = seg_col[s], o0 = seg_off[s];
@@ -506,13 +557,25 @@ __global__ __launch_bounds__(kBlock) void spmv_window_vi_kernel(
     int64_t kb[R + 1];
 #pragma unroll
     for (int i = 0; i <= R; ++i) kb[i] = rp[r0 + i < row_end ? r0 + i : row_end];  // wave-uniform
+    uint32_t ks[R];
+    int32_t len[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      ks[i] = (uint32_t)(kb[i] - kb[0]);
+      len[i] = (int32_t)(kb[i + 1] - kb[i]);
+    }
+    const uint16_t *lcol_b = lcol + kb[0];
+    const uint8_t *vidx_b = vidx + kb[0];
+    const uint16_t *vidw_b = vidw + kb[0];
+    const int32_t *col_b = col + kb[0];
+    const double *val_b = val + kb[0];
     double acc[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) acc[i] = 0.0;
-    if (mode == 3) vi_rows<R, J, 3>(kb, lane, lcol, vidx, col, val, xs, ds, x, x_halo, n_local, acc);
-    else if (mode == 0) vi_rows<R, J, 0>(kb, lane, lcol, vidx, col, val, xs, ds, x, x_halo, n_local, acc);
-    else if (mode == 1) vi_rows<R, J, 1>(kb, lane, lcol, vidx, col, val, xs, ds, x, x_halo, n_local, acc);
-    else vi_rows<R, J, 2>(kb, lane, lcol, vidx, col, val, xs, ds, x, x_halo, n_local, acc);
+    if (mode == 3) vi_rows<R, J, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
+    else if (mode == 0) vi_rows<R, J, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
+    else if (mode == 1) vi_rows<R, J, 1>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
+    else vi_rows<R, J, 2>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
     // rows past row_end have no entries (acc = 0) and are not written
     static_assert(R == 2 || R == 4, "row batches of 2 or 4");
     double s;
@@ -529,6 +592,132 @@ __global__ __launch_bounds__(kBlock) void spmv_window_vi_kernel(
       writer = (lane & 31) == 0;
     }
     if (writer && r < row_end) {
+      if (EPI == 0)
+        y[r] = s;
+      else if (EPI == 1)
+        y[r] = fma(alpha, s, y[r]);
+      else if (EPI == 2)
+        y[r] = d[r] * s;
+      else {
+        y[r] = s;
+        y2[r] = d[r] * s;
+      }
+    }
+  }
+}
+
+// Class-batched variant (the default for value-indexed matrices).  At upload the rows of
+// every block are grouped by their chunk count ceil(len / 64) into batches of 4 rows (a
+// 32-byte descriptor per batch: per row its entry offset, length and block-local row id).
+// A wave runs the batch through code specialised for that class -- straight-line, no
+// guards -- and writes the four sums to the rows the descriptor names.  Rows keep their
+// canonical lane assignment and fma order, so the result is unchanged; only the order in
+// which a block's rows are visited differs.
+constexpr int kVibMaxClass = 6;   // classes 0..6 are specialised, longer rows take the generic path
+template <int EPI>
+__global__ __launch_bounds__(kBlock) void spmv_window_vib_kernel(
+    int64_t nrows, int32_t RB, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+    const uint16_t *__restrict__ lcol, const double *__restrict__ val,
+    const int32_t *__restrict__ blk_seg_begin, const int32_t *__restrict__ blk_W,
+    const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
+    const double *__restrict__ x, const double *__restrict__ x_halo, int32_t n_local,
+    double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2,
+    const uint8_t *__restrict__ vidx, const uint16_t *__restrict__ vidw,
+    const int32_t *__restrict__ blk_dict_off, const int32_t *__restrict__ blk_dict_n,
+    const double *__restrict__ dict, int32_t dict_lds_off,
+    const uint64_t *__restrict__ btab, const int32_t *__restrict__ bcnt, int32_t bstride) {
+  extern __shared__ double xs[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t b = blockIdx.x;
+  const int32_t W = blk_W[b];
+  const double *ds = xs + dict_lds_off;
+  int mode = 2;  // block-uniform
+  if (W >= 0) {
+    const int32_t nd = blk_dict_n[b];
+    mode = nd < 0 ? 1 : ((nd & kDictWide) ? 3 : 0);
+    const int32_t ndv = nd & 0xffff;
+    if (nd >= 0)
+      for (int t = threadIdx.x; t < ndv; t += kBlock) xs[dict_lds_off + t] = dict[blk_dict_off[b] + t];
+    const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
+    for (int32_t s = s0 + wave; s < s1; s += 4) {
+      const int32_t c0 = seg_col[s], o0 = seg_off[s];
+      const int32_t len = ((s + 1 < s1) ? seg_off[s + 1] : W) - o0;
+      for (int32_t i = lane; i < len; i += 64) {
+        const int32_t c = c0 + i;
+        xs[o0 + i] = (c < n_local) ? x[c] : x_halo[c - n_local];
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t row_begin = b * RB;
+  const int64_t k_blk = rp[row_begin];
+  const uint16_t *lcol_b = lcol + k_blk;
+  const uint8_t *vidx_b = vidx + k_blk;
+  const uint16_t *vidw_b = vidw + k_blk;
+  const int32_t *col_b = col + k_blk;
+  const double *val_b = val + k_blk;
+  const int32_t nbatch = bcnt[b];
+  // batch descriptor: 4 x uint64 = {entry offset from the block start (32) | entry count (16) |
+  // block-local row id, 0xFF = filler (8) | class (8)}; the next batch's descriptor is
+  // fetched while the current one is processed (one s_load_dwordx8 each)
+  const uint64_t *bt = btab + (b * bstride + wave) * 4;
+  uint64_t nx[4] = {0, 0, 0, 0};
+  if (wave < nbatch) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nx[i] = bt[i];
+  }
+  for (int32_t bi = wave; bi < nbatch; bi += 4) {
+    uint64_t desc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) desc[i] = nx[i];
+    bt += 16;
+    if (bi + 4 < nbatch) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nx[i] = bt[i];
+    }
+    const int cls = (int)(desc[0] >> 56);
+    uint32_t ks[4];
+    int32_t len[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ks[i] = (uint32_t)desc[i];
+      len[i] = (int32_t)((desc[i] >> 32) & 0xffff);
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (mode == 0) {
+      switch (cls) {
+        case 0: break;
+        case 1: vib_rows<1, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 2: vib_rows<2, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 3: vib_rows<3, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 4: vib_rows<4, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 5: vib_rows<5, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 6: vib_rows<6, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        default: vi_rows<4, 2, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
+      }
+    } else if (mode == 3) {
+      switch (cls) {
+        case 0: break;
+        case 1: vib_rows<1, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 2: vib_rows<2, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 3: vib_rows<3, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 4: vib_rows<4, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 5: vib_rows<5, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        case 6: vib_rows<6, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, xs, ds, acc); break;
+        default: vi_rows<4, 2, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
+      }
+    } else if (mode == 1) {
+      vi_rows<4, 2, 1>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
+    } else {
+      vi_rows<4, 2, 2>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
+    }
+    const double s = reduce_rows4(acc[0], acc[1], acc[2], acc[3]);
+    const int q = lane >> 4;  // 16-lane row q holds the tree of batch row {0, 2, 1, 3}[q]
+    const uint64_t dq = q == 0 ? desc[0] : (q == 1 ? desc[2] : (q == 2 ? desc[1] : desc[3]));
+    const int id = (int)((dq >> 48) & 0xff);
+    if ((lane & 15) == 0 && id != 0xff) {
+      const int64_t r = row_begin + id;
       if (EPI == 0)
         y[r] = s;
       else if (EPI == 1)

@@ -302,7 +302,7 @@ int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launc
 typedef struct alfd_matrix_info {
   int32_t lanes, windowed, value_indexed, reserved;
   int64_t nnz, window_blocks, window_fallback_blocks;
-  int64_t value_indexed_blocks, value_indexed_nnz, dictionary_entries, value_escapes;
+  int64_t value_indexed_blocks, value_indexed_nnz, dictionary_entries, value_wide_nnz;
   double algorithmic_bytes, streamed_bytes;
 } alfd_matrix_info;
 int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out);

@@ -71,18 +71,22 @@ def test_spmv_every_kernel_family_bitwise(built):
     big = problems.generate(dim=3, degree=2, ncomp=3, n_cells=20, stokes=False, grad_div=True,
                             gamma_grad_div=10.0, radius=0.1, immersed_refine=0)
     mats["windowed"] = big.mats["A"]       # 206763 rows >= 96*2048 -> LDS-windowed kernel
-    # value-indexed forms of the same matrix: a block dictionary (as uploaded), escape-coded blocks
-    # (5% of the entries made unique) and raw blocks (40% unique); fully random values -> no dictionary
+    # value-indexed forms of the same matrix: 8-bit codes (as uploaded), 16-bit codes (every value
+    # scaled by one of 9 factors: ~400 distinct per block) and raw blocks (40% unique values in the
+    # first 30% of the rows); fully random values -> no dictionary
     expect_format = {"windowed": "dict"}
     for name, share in (("win_escape", 0.05), ("win_rawblocks", 0.4), ("win_novi", 1.0)):
         a = big.mats["A"]
         v = np.array(a.val, copy=True)
         pick = rng.random(v.size) < share
+        if name == "win_escape":                    # 16-bit codes
+            v *= (1.0 + 0.125 * rng.integers(0, 9, v.size))
+            pick[:] = False
         if name == "win_rawblocks":                 # only the first 30% of the rows: those blocks go raw
             pick[int(a.row_ptr[int(0.3 * a.nrows)]):] = False
         v[pick] = rng.uniform(-1, 1, int(pick.sum()))
         mats[name] = problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), v)
-        expect_format[name] = {"win_escape": "escape", "win_rawblocks": "raw", "win_novi": "none"}[name]
+        expect_format[name] = {"win_escape": "wide", "win_rawblocks": "raw", "win_novi": "none"}[name]
     # short-row window kernel (L-lane groups): L = 32 (27-point), 16 (2-D Q2), 8 (9-point), and a
     # ragged banded matrix with empty rows plus far-away columns (blocks that fall back to global x)
     mats["win32"] = problems.generate(dim=3, degree=1, ncomp=1, n_cells=74, radius=0.1).mats["A"]
@@ -104,9 +108,9 @@ def test_spmv_every_kernel_family_bitwise(built):
             info = ctx.matrix_info(_abi.A)
             fmt = expect_format.get(name)
             if fmt == "dict":
-                assert info["value_indexed"] and info["value_escapes"] == 0 and info["value_indexed_nnz"] == m.nnz
-            elif fmt == "escape":
-                assert info["value_indexed"] and 0 < info["value_escapes"] < m.nnz // 8
+                assert info["value_indexed"] and info["value_wide_nnz"] == 0 and info["value_indexed_nnz"] == m.nnz
+            elif fmt == "wide":
+                assert info["value_indexed"] and info["value_wide_nnz"] > m.nnz // 2
             elif fmt == "raw":
                 assert info["value_indexed"] and 0 < info["value_indexed_blocks"] < info["window_blocks"]
             elif fmt == "none":
