@@ -89,6 +89,7 @@ def main():
     # (prm:23); with the Chebyshev/Jacobi sweep north_star prescribes the count
     # grows like 1/h, so the cap is raised (stated in DESIGN.md section 6).
     cfg.inner.max_steps = args.inner_max
+    cfg.log_level = int(os.environ.get("ALFD_BENCH_LOG_LEVEL", "0"))
     aggregates = levels = None
     if args.inner_prec == "multilevel":
         cfg.inner_prec = _abi.PREC_MULTILEVEL
@@ -197,7 +198,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("spmv_window_vi_kernel<4,2,0> (A, LDS-windowed CSR, dictionary-coded values)"
+            "kernel": ("spmv_window_vib_kernel<0,0,4> (A, LDS-windowed CSR, dictionary-coded values, class-batched rows)"
                        if info["value_indexed"] else "spmv_window_kernel<2,8,0,0> (A, LDS-windowed CSR)"),
             # achieved = plain-CSR algorithmic bytes / measured launch time.  With
             # dictionary-coded values the kernel streams fewer bytes than that (streamed_*), so

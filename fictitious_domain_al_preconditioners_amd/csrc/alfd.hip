@@ -223,6 +223,9 @@ struct alfd_ctx {
   int spmv_group_R = 4, spmv_group_U = 4;  // batch shape of the short-row window kernel
   bool vi_off = false;                      // alfd_bench_spmv_format: time the plain 10 B/nnz kernel on a value-indexed matrix
   int vi_rows_R = 4, vi_rows_J = 2;         // row-batched VI kernel shape (ALFD_SPMV_VI_R=0: stream-ordered VI kernel)
+  int vi_xcd = 0;                           // XCD-contiguous row-block order in the class-batched kernel
+  int vi_levels = 1;                        // also dictionary-code multigrid level matrices
+                        // waves per workgroup of the class-batched kernel (4 or 8)
   int vi_batched = 1;                       // class-batched VI kernel (ALFD_SPMV_VI_BATCHED=0: in-order batches)
   int win_RB_vi = 96;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
@@ -447,15 +450,23 @@ static void launch_window(alfd_ctx *ctx, const DevCsr &m, const double *x, doubl
                      m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->win_xcd)
   const bool vi = m.vi && !ctx->vi_off;
   if (vi && ctx->vi_batched && m.vib_tab) {
-#define ALFD_VIB(EPI)                                                                                         \
-  hipLaunchKernelGGL((spmv_window_vib_kernel<EPI>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds,        \
+#define ALFD_VIB(EPI, TAG)                                                                                    \
+  hipLaunchKernelGGL((spmv_window_vib_kernel<EPI, TAG>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds,   \
                      ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin, m.blk_W,    \
-                     m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, m.vidx, m.vidw, \
-                     m.blk_dict_off, m.blk_dict_n, m.dict, m.win_maxW, m.vib_tab, m.vib_cnt, m.vib_stride)
-    if (epi == 0) ALFD_VIB(0);
-    else if (epi == 1) ALFD_VIB(1);
-    else if (epi == 2) ALFD_VIB(2);
-    else ALFD_VIB(3);
+                     m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, m.vidx, m.vidw,        \
+                     m.blk_dict_off, m.blk_dict_n, m.dict, m.win_maxW, m.vib_tab, m.vib_cnt, m.vib_stride,    \
+                     ctx->vi_xcd)
+    if (m.tag == 0) {
+      if (epi == 0) ALFD_VIB(0, 0);
+      else if (epi == 1) ALFD_VIB(1, 0);
+      else if (epi == 2) ALFD_VIB(2, 0);
+      else ALFD_VIB(3, 0);
+    } else {
+      if (epi == 0) ALFD_VIB(0, 1);
+      else if (epi == 1) ALFD_VIB(1, 1);
+      else if (epi == 2) ALFD_VIB(2, 1);
+      else ALFD_VIB(3, 1);
+    }
 #undef ALFD_VIB
     return;
   }
@@ -1306,7 +1317,7 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
                         bool slot_is_user) {
   // short rows: larger row blocks, so a window serves about as many entries as for L = 64
   int RB = short_row_block(ctx, m.L);
-  const bool vi_candidate = ctx->win_vi && m.L == 64 && slot_is_user;
+  const bool vi_candidate = ctx->win_vi && m.L == 64 && (slot_is_user || ctx->vi_levels);
   if (vi_candidate && ctx->win_RB_vi > 0 && ctx->win_RB_vi != RB) {
     // The value-indexed kernel is latency-bound, not HBM-bound, and prefers smaller row blocks
     // (smaller windows, more resident workgroups).  Sample a few blocks: if their values
@@ -1536,6 +1547,9 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
         m.vib_stride = stride;
       }
       m.vi = true;
+      if (ctx->cfg.log_level > 0)
+        std::fprintf(stderr, "[alfd] value-indexed %s matrix: %lld rows, %lld of %lld blocks coded, dict %zu\n",
+                     slot_is_user ? "user" : "level", (long long)m.nrows, (long long)nvb, (long long)nb, dict.size());
       m.vi_blocks = nvb;
       m.vi_nnz = nvn;
       m.vi_dict_total = (int64_t)dict.size();
@@ -2412,6 +2426,8 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW")) ctx->win_enable = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB")) ctx->win_RB = std::max(4, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
+  if (const char *e = std::getenv("ALFD_SPMV_VI_LEVELS")) ctx->vi_levels = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_VI_XCD")) ctx->vi_xcd = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_BATCHED")) ctx->vi_batched = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB_VI")) ctx->win_RB_vi = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_R")) ctx->vi_rows_R = std::atoi(e);

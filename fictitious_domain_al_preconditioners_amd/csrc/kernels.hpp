@@ -614,8 +614,11 @@ __global__ __launch_bounds__(kBlock) void spmv_window_vi_kernel(
 // canonical lane assignment and fma order, so the result is unchanged; only the order in
 // which a block's rows are visited differs.
 constexpr int kVibMaxClass = 6;   // classes 0..6 are specialised, longer rows take the generic path
-template <int EPI>
-__global__ __launch_bounds__(kBlock) void spmv_window_vib_kernel(
+// The register budget is capped at 64 VGPRs so that 8 waves fit a SIMD (only the rare
+// generic paths spill).  TAG only separates the fine operator (0) from multigrid level
+// matrices (1) in profiler summaries.
+template <int EPI, int TAG = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_window_vib_kernel(
     int64_t nrows, int32_t RB, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
     const uint16_t *__restrict__ lcol, const double *__restrict__ val,
     const int32_t *__restrict__ blk_seg_begin, const int32_t *__restrict__ blk_W,
@@ -625,11 +628,18 @@ __global__ __launch_bounds__(kBlock) void spmv_window_vib_kernel(
     const uint8_t *__restrict__ vidx, const uint16_t *__restrict__ vidw,
     const int32_t *__restrict__ blk_dict_off, const int32_t *__restrict__ blk_dict_n,
     const double *__restrict__ dict, int32_t dict_lds_off,
-    const uint64_t *__restrict__ btab, const int32_t *__restrict__ bcnt, int32_t bstride) {
+    const uint64_t *__restrict__ btab, const int32_t *__restrict__ bcnt, int32_t bstride, int xcd_remap) {
   extern __shared__ double xs[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t b = blockIdx.x;
+  // Workgroups with equal blockIdx % 8 share an XCD and its L2.  With 3 B/nnz the x windows are
+  // a third of the traffic, and neighbouring row blocks share most of their window: give each
+  // XCD a contiguous run of row blocks so that the overlap hits in that XCD's L2.
+  int64_t b = blockIdx.x;
+  if (xcd_remap) {
+    const int64_t nwg = gridDim.x, q = nwg / 8, rm = nwg % 8, xcd = b % 8, idx = b / 8;
+    b = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + idx;
+  }
   const int32_t W = blk_W[b];
   const double *ds = xs + dict_lds_off;
   int mode = 2;  // block-uniform
@@ -638,9 +648,9 @@ __global__ __launch_bounds__(kBlock) void spmv_window_vib_kernel(
     mode = nd < 0 ? 1 : ((nd & kDictWide) ? 3 : 0);
     const int32_t ndv = nd & 0xffff;
     if (nd >= 0)
-      for (int t = threadIdx.x; t < ndv; t += kBlock) xs[dict_lds_off + t] = dict[blk_dict_off[b] + t];
+      for (int t = threadIdx.x; t < ndv; t += 64 * NW) xs[dict_lds_off + t] = dict[blk_dict_off[b] + t];
     const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
-    for (int32_t s = s0 + wave; s < s1; s += 4) {
+    for (int32_t s = s0 + wave; s < s1; s += NW) {
       const int32_t c0 = seg_col[s], o0 = seg_off[s];
       const int32_t len = ((s + 1 < s1) ? seg_off[s + 1] : W) - o0;
       for (int32_t i = lane; i < len; i += 64) {
@@ -667,12 +677,12 @@ __global__ __launch_bounds__(kBlock) void spmv_window_vib_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) nx[i] = bt[i];
   }
-  for (int32_t bi = wave; bi < nbatch; bi += 4) {
+  for (int32_t bi = wave; bi < nbatch; bi += NW) {
     uint64_t desc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) desc[i] = nx[i];
-    bt += 16;
-    if (bi + 4 < nbatch) {
+    bt += 4 * NW;
+    if (bi + NW < nbatch) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) nx[i] = bt[i];
     }
