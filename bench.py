@@ -44,6 +44,7 @@ def main():
                     default=os.environ.get("ALFD_BENCH_PREC", "multilevel"))
     ap.add_argument("--ml-smooth-degree", type=int, default=2)
     ap.add_argument("--ml-smooth-ratio", type=float, default=8.0)
+    ap.add_argument("--ml-coarse-degree", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only-spmv", type=int, default=0,
                     help="skip the solve; run this many back-to-back A SpMV launches (for rocprofv3)")
@@ -94,6 +95,7 @@ def main():
     if args.inner_prec == "multilevel":
         cfg.inner_prec = _abi.PREC_MULTILEVEL
         cfg.ml_smooth_degree, cfg.ml_smooth_ratio = args.ml_smooth_degree, args.ml_smooth_ratio
+        cfg.ml_coarse_degree = args.ml_coarse_degree
 
     t0 = time.time()
     ctx = solver.Context(local_rank)
@@ -192,6 +194,7 @@ def main():
             "final_residual": last.last_residual, "initial_residual": last.initial_residual,
             "inner_prec": (f"chebyshev({cfg.cheb_degree})-jacobi" if cfg.inner_prec == _abi.PREC_CHEBYSHEV else
                            f"aggregation-multigrid V-cycle, chebyshev({cfg.ml_smooth_degree}) smoothing, "
+                           f"chebyshev({cfg.ml_coarse_degree}) coarsest solve, "
                            f"levels {[lv[1] for lv in levels]}"),
             "inner_max_steps": cfg.inner.max_steps,
             "restart": cfg.restart, "partition": f"row-slabs x{world}",

@@ -79,6 +79,15 @@ class MatrixInfo(C.Structure):
     ]
 
 
+class WindowPlanInfo(C.Structure):
+    _fields_ = [
+        ("windowed", C.c_int32), ("value_indexed", C.c_int32), ("row_block", C.c_int32), ("max_window", C.c_int32),
+        ("blocks", C.c_int64), ("fallback_blocks", C.c_int64), ("segments", C.c_int64),
+        ("value_indexed_blocks", C.c_int64), ("value_indexed_nnz", C.c_int64), ("value_wide_nnz", C.c_int64),
+        ("dictionary_entries", C.c_int64), ("batches", C.c_int64), ("decode_mismatches", C.c_int64),
+    ]
+
+
 def default_config(variant=AL_STOKES) -> Config:
     """Same defaults as alfd_default_config(): the reference's solver knobs
     (parameters_stokes_3d.prm:17-24,150-157; immersed_laplace.cc:907; elliptic...:863)."""

@@ -1310,23 +1310,46 @@ static void host_halo_plan(int64_t nnz, const int32_t *col, const int64_t *col_o
 
 // Build the LDS-window format of a long-row matrix (host, multi-threaded).
 // col: column indices in the LOCAL index space [local | halo].
-static int short_row_block(const alfd_ctx *ctx, int L) {
-  return L == 64 ? ctx->win_RB : std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / L);
-}
-static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col, const double *val,
-                        bool slot_is_user) {
+// ---- window / value-index format: pure host planning (also exported as
+// alfd_host_window_plan so that CPU tests can decode and check it), then upload.
+struct WindowParams {
+  int RB_long = 96, short_scale = 2, RB_vi = 96, maxW = 4096, gap = 8;
+  bool want_vi = true;
+};
+struct WindowPlan {
+  bool win = false, vi = false;
+  int RB = 0;
+  int32_t maxW = 0;
+  int64_t nb = 0, fallback = 0;
+  std::vector<uint16_t> lcol;
+  std::vector<int32_t> blkW, seg_begin, seg_col, seg_off;
+  std::vector<uint8_t> vidx;
+  std::vector<uint16_t> vidw;
+  std::vector<int32_t> blk_dn, doff;
+  std::vector<double> dict;
+  int64_t vi_blocks = 0, vi_nnz = 0, wide_nnz = 0;
+  std::vector<uint64_t> tab;
+  std::vector<int32_t> cnt;
+  int stride = 0;
+};
+static int window_row_block(const WindowParams &wp, int L) {
   // short rows: larger row blocks, so a window serves about as many entries as for L = 64
-  int RB = short_row_block(ctx, m.L);
-  const bool vi_candidate = ctx->win_vi && m.L == 64 && (slot_is_user || ctx->vi_levels);
-  if (vi_candidate && ctx->win_RB_vi > 0 && ctx->win_RB_vi != RB) {
-    // The value-indexed kernel is latency-bound, not HBM-bound, and prefers smaller row blocks
-    // (smaller windows, more resident workgroups).  Sample a few blocks: if their values
-    // look dictionary-codable, build the window format with the smaller block.
-    const int64_t nb96 = (m.nrows + RB - 1) / RB;
+  return L == 64 ? wp.RB_long : std::min(512, wp.RB_long * wp.short_scale * 64 / L);
+}
+
+static void plan_window(int64_t nrows, int L, const int64_t *rp, const int32_t *col, const double *val,
+                        const WindowParams &wp, WindowPlan &pl) {
+  const int64_t nnz = rp[nrows];
+  int RB = window_row_block(wp, L);
+  const bool want_vi = wp.want_vi && L == 64;
+  if (want_vi && wp.RB_vi > 0 && wp.RB_vi != RB) {
+    // The value-indexed kernel has its own best block size.  Sample a few blocks: if their
+    // values look dictionary-codable, build the window format with that block.
+    const int64_t nb0 = (nrows + RB - 1) / RB;
     int good = 0, seen = 0;
-    for (int64_t q = 0; q < 32 && q < nb96; ++q) {
-      const int64_t b = nb96 * q / std::min<int64_t>(32, nb96);
-      const int64_t k0 = rp[b * RB], k1 = rp[std::min<int64_t>((b + 1) * RB, m.nrows)];
+    for (int64_t q = 0; q < 32 && q < nb0; ++q) {
+      const int64_t b = nb0 * q / std::min<int64_t>(32, nb0);
+      const int64_t k0 = rp[b * RB], k1 = rp[std::min<int64_t>((b + 1) * RB, nrows)];
       std::unordered_set<uint64_t> u;
       for (int64_t k = k0; k < k1 && u.size() <= 1024; ++k) {
         uint64_t bits;
@@ -1336,19 +1359,20 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
       ++seen;
       good += u.size() <= 1024;
     }
-    if (good * 4 >= seen * 3) RB = ctx->win_RB_vi;
+    if (good * 4 >= seen * 3) RB = wp.RB_vi;
   }
-  const int maxW = ctx->win_maxW, GAP = ctx->win_gap;
-  const int64_t nb = (m.nrows + RB - 1) / RB;
-  if (nb == 0 || nb > 2147483000LL) return ALFD_OK;
-  std::vector<uint16_t> lcol(m.nnz);
-  std::vector<int32_t> blkW(nb), blk_nseg(nb);
-  // value dictionaries: long-row fine operators only (level matrices are Galerkin products)
-  const bool want_vi = vi_candidate;
-  std::vector<uint8_t> vidx(want_vi ? m.nnz : 0);
-  std::vector<int32_t> blk_dn(nb, -1);
+  const int maxW = wp.maxW, GAP = wp.gap;
+  const int64_t nb = (nrows + RB - 1) / RB;
+  if (nb == 0 || nb > 2147483000LL) return;
+  pl.RB = RB;
+  pl.nb = nb;
+  pl.lcol.assign(nnz, 0);
+  pl.blkW.assign(nb, 0);
+  std::vector<int32_t> blk_nseg(nb, 0);
+  pl.vidx.assign(want_vi ? nnz : 0, 0);
+  pl.vidw.assign(want_vi ? nnz : 0, 0);  // 16-bit codes (uploaded only if some block needs them)
+  pl.blk_dn.assign(nb, -1);
   std::vector<std::vector<double>> t_dict(want_vi ? nb : 0);
-  std::vector<uint16_t> vidw(want_vi ? m.nnz : 0);  // 16-bit codes (kept only if some block needs them)
   std::vector<int64_t> t_wide(64, 0);
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::vector<int32_t>> t_seg_col(T), t_seg_off(T);
@@ -1359,10 +1383,8 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
       std::vector<uint8_t> mark;
       std::vector<int32_t> pos;
       for (int64_t b = b0; b < b1; ++b) {
-        const int64_t r0 = b * RB, r1 = std::min<int64_t>(r0 + RB, m.nrows);
+        const int64_t r0 = b * RB, r1 = std::min<int64_t>(r0 + RB, nrows);
         const int64_t k0 = rp[r0], k1 = rp[r1];
-        blkW[b] = 0;
-        blk_nseg[b] = 0;
         if (k1 == k0) continue;
         int32_t clo = INT32_MAX, chi = -1;
         for (int64_t k = k0; k < k1; ++k) {
@@ -1371,7 +1393,7 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
         }
         const int64_t range = (int64_t)chi - clo + 1;
         if (range > (int64_t)(1 << 22)) {
-          blkW[b] = -1;
+          pl.blkW[b] = -1;
           continue;
         }
         mark.assign(range, 0);
@@ -1401,12 +1423,12 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
         if (W > maxW || W > 65535) {
           t_seg_col[t].resize(seg_base);
           t_seg_off[t].resize(seg_base);
-          blkW[b] = -1;
+          pl.blkW[b] = -1;
           continue;
         }
-        blkW[b] = W;
+        pl.blkW[b] = W;
         blk_nseg[b] = nseg;
-        for (int64_t k = k0; k < k1; ++k) lcol[k] = (uint16_t)pos[col[k] - clo];
+        for (int64_t k = k0; k < k1; ++k) pl.lcol[k] = (uint16_t)pos[col[k] - clo];
         if (want_vi) {
           // open-addressing table over the 64-bit patterns.  Up to 256 distinct values:
           // 8-bit codes; up to kDictMaxEntries: 16-bit codes; beyond that: raw block.
@@ -1433,128 +1455,137 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
               if (keys[h] == bits) break;
               h = (h + 1) & (kTab - 1);
             }
-            if (ok) vidw[k] = (uint16_t)ids[h];
+            if (ok) pl.vidw[k] = (uint16_t)ids[h];
           }
           if (!ok) {
             dv.clear();
           } else if (dv.size() <= 256) {
-            for (int64_t k = k0; k < k1; ++k) vidx[k] = (uint8_t)vidw[k];
-            blk_dn[b] = (int32_t)dv.size();
+            for (int64_t k = k0; k < k1; ++k) pl.vidx[k] = (uint8_t)pl.vidw[k];
+            pl.blk_dn[b] = (int32_t)dv.size();
           } else {
-            blk_dn[b] = (int32_t)dv.size() | kDictWide;
+            pl.blk_dn[b] = (int32_t)dv.size() | kDictWide;
             t_wide[t] += k1 - k0;
           }
         }
       }
     });
   for (auto &x : th) x.join();
-  std::vector<int32_t> seg_begin(nb + 1, 0), seg_col, seg_off;
-  for (int64_t b = 0; b < nb; ++b) seg_begin[b + 1] = seg_begin[b] + blk_nseg[b];
+  pl.seg_begin.assign(nb + 1, 0);
+  for (int64_t b = 0; b < nb; ++b) pl.seg_begin[b + 1] = pl.seg_begin[b] + blk_nseg[b];
   for (int t = 0; t < T; ++t) {
-    seg_col.insert(seg_col.end(), t_seg_col[t].begin(), t_seg_col[t].end());
-    seg_off.insert(seg_off.end(), t_seg_off[t].begin(), t_seg_off[t].end());
+    pl.seg_col.insert(pl.seg_col.end(), t_seg_col[t].begin(), t_seg_col[t].end());
+    pl.seg_off.insert(pl.seg_off.end(), t_seg_off[t].begin(), t_seg_off[t].end());
   }
   int32_t mw = 0;
-  int64_t fb = 0;
   for (int64_t b = 0; b < nb; ++b) {
-    mw = std::max(mw, blkW[b]);
-    fb += blkW[b] < 0;
+    mw = std::max(mw, pl.blkW[b]);
+    pl.fallback += pl.blkW[b] < 0;
   }
-  if (fb * 2 > nb) return ALFD_OK;  // windows do not pay for this matrix: keep the plain kernels
-  m.win_RB = RB;
-  m.win_maxW = std::max(mw, 1);
-  m.win_nblocks = nb;
-  m.win_fallback_blocks = fb;
-  m.win_nseg = (int64_t)seg_col.size();
-  RC(csr_alloc(ctx, m, &m.lcol, m.nnz));
-  RC(csr_alloc(ctx, m, &m.blk_seg_begin, nb + 1));
-  RC(csr_alloc(ctx, m, &m.blk_W, nb));
-  RC(csr_alloc(ctx, m, &m.seg_col, m.win_nseg));
-  RC(csr_alloc(ctx, m, &m.seg_off, m.win_nseg));
-  HIPC(hipMemcpyAsync(m.lcol, lcol.data(), m.nnz * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
-  HIPC(hipMemcpyAsync(m.blk_seg_begin, seg_begin.data(), (nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPC(hipMemcpyAsync(m.blk_W, blkW.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPC(hipMemcpyAsync(m.seg_col, seg_col.data(), m.win_nseg * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPC(hipMemcpyAsync(m.seg_off, seg_off.data(), m.win_nseg * 4, hipMemcpyHostToDevice, ctx->stream));
+  pl.maxW = std::max(mw, 1);
+  if (pl.fallback * 2 > nb) return;  // windows do not pay for this matrix: keep the plain kernels
+  pl.win = true;
+  if (!want_vi) return;
+  pl.doff.assign(nb, 0);
+  for (int64_t b = 0; b < nb; ++b) {
+    pl.doff[b] = (int32_t)pl.dict.size();
+    if (pl.blk_dn[b] < 0) continue;
+    pl.dict.insert(pl.dict.end(), t_dict[b].begin(), t_dict[b].end());
+    ++pl.vi_blocks;
+    pl.vi_nnz += rp[std::min<int64_t>((b + 1) * RB, nrows)] - rp[b * RB];
+  }
+  for (int64_t e : t_wide) pl.wide_nnz += e;
+  if (!(pl.vi_blocks * 2 > nb && pl.dict.size() < 2000000000ull)) return;  // worthwhile only if most blocks are coded
+  pl.vi = true;
+  int64_t longest = 0;
+  for (int64_t r = 0; r < nrows; ++r) longest = std::max(longest, rp[r + 1] - rp[r]);
+  if (RB > 250 || longest > 65535) return;
+  // class-sorted batches of 4 rows per block
+  const int stride = (RB + 3) / 4 + kVibMaxClass + 2;
+  pl.stride = stride;
+  pl.tab.assign((size_t)nb * stride * 4, 0);
+  pl.cnt.assign(nb, 0);
+  std::vector<std::thread> th2;
+  for (int t = 0; t < T; ++t)
+    th2.emplace_back([&, t]() {
+      std::vector<int> ids[kVibMaxClass + 2];
+      for (int64_t b = nb * t / T; b < nb * (t + 1) / T; ++b) {
+        const int64_t r0 = b * RB, r1 = std::min<int64_t>(r0 + RB, nrows);
+        for (auto &v : ids) v.clear();
+        for (int64_t r = r0; r < r1; ++r) {
+          const int64_t len = rp[r + 1] - rp[r];
+          const int64_t cls = (len + 63) / 64;
+          ids[cls > kVibMaxClass ? kVibMaxClass + 1 : cls].push_back((int)(r - r0));
+        }
+        int nbt = 0;
+        for (int cls = 0; cls <= kVibMaxClass + 1; ++cls)
+          for (size_t q = 0; q < ids[cls].size(); q += 4) {
+            uint64_t *dst = &pl.tab[((size_t)b * stride + nbt++) * 4];
+            for (int i = 0; i < 4; ++i) {
+              const bool real = q + i < ids[cls].size();
+              const int id = ids[cls][real ? q + i : q];  // filler: repeat the batch's first row
+              const uint64_t ks = (uint64_t)(rp[r0 + id] - rp[r0]);
+              const uint64_t len = (uint64_t)(rp[r0 + id + 1] - rp[r0 + id]);
+              dst[i] = ks | (len << 32) | ((uint64_t)(real ? id : 0xff) << 48) | ((uint64_t)cls << 56);
+            }
+          }
+        pl.cnt[b] = nbt;
+      }
+    });
+  for (auto &x : th2) x.join();
+}
+
+template <class T>
+static int upload_vec(alfd_ctx *ctx, DevCsr &m, T **dst, const std::vector<T> &v) {
+  RC(csr_alloc(ctx, m, dst, (int64_t)v.size()));
+  HIPC(hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return ALFD_OK;
+}
+
+static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col, const double *val,
+                        bool slot_is_user) {
+  WindowParams wp;
+  wp.RB_long = ctx->win_RB;
+  wp.short_scale = ctx->win_short_scale;
+  wp.RB_vi = ctx->win_RB_vi;
+  wp.maxW = ctx->win_maxW;
+  wp.gap = ctx->win_gap;
+  wp.want_vi = ctx->win_vi && (slot_is_user || ctx->vi_levels);
+  WindowPlan pl;
+  plan_window(m.nrows, m.L, rp, col, val, wp, pl);
+  if (!pl.win) return ALFD_OK;
+  m.win_RB = pl.RB;
+  m.win_maxW = pl.maxW;
+  m.win_nblocks = pl.nb;
+  m.win_fallback_blocks = pl.fallback;
+  m.win_nseg = (int64_t)pl.seg_col.size();
+  RC(upload_vec(ctx, m, &m.lcol, pl.lcol));
+  RC(upload_vec(ctx, m, &m.blk_seg_begin, pl.seg_begin));
+  RC(upload_vec(ctx, m, &m.blk_W, pl.blkW));
+  RC(upload_vec(ctx, m, &m.seg_col, pl.seg_col));
+  RC(upload_vec(ctx, m, &m.seg_off, pl.seg_off));
   HIPC(hipStreamSynchronize(ctx->stream));
   m.win = true;
-  if (want_vi) {
-    std::vector<int32_t> doff(nb, 0);
-    std::vector<double> dict;
-    int64_t nvb = 0, nvn = 0;
-    for (int64_t b = 0; b < nb; ++b) {
-      doff[b] = (int32_t)dict.size();
-      if (blk_dn[b] < 0) continue;
-      dict.insert(dict.end(), t_dict[b].begin(), t_dict[b].end());
-      ++nvb;
-      nvn += rp[std::min<int64_t>((b + 1) * RB, m.nrows)] - rp[b * RB];
-    }
-    for (int64_t e : t_wide) m.vi_wide_nnz += e;
-    if (nvb * 2 > nb && dict.size() < 2000000000ull) {  // worthwhile: most blocks are dictionary-coded
-      RC(csr_alloc(ctx, m, &m.vidx, m.nnz));
-      RC(csr_alloc(ctx, m, &m.blk_dict_off, nb));
-      RC(csr_alloc(ctx, m, &m.blk_dict_n, nb));
-      RC(csr_alloc(ctx, m, &m.dict, (int64_t)dict.size()));
-      HIPC(hipMemcpyAsync(m.vidx, vidx.data(), m.nnz, hipMemcpyHostToDevice, ctx->stream));
-      if (m.vi_wide_nnz > 0) {
-        RC(csr_alloc(ctx, m, &m.vidw, m.nnz));
-        HIPC(hipMemcpyAsync(m.vidw, vidw.data(), m.nnz * 2, hipMemcpyHostToDevice, ctx->stream));
-      }
-      HIPC(hipMemcpyAsync(m.blk_dict_off, doff.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
-      HIPC(hipMemcpyAsync(m.blk_dict_n, blk_dn.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
-      HIPC(hipMemcpyAsync(m.dict, dict.data(), dict.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-      HIPC(hipStreamSynchronize(ctx->stream));
-      int64_t longest = 0;
-      for (int64_t r = 0; r < m.nrows; ++r) longest = std::max(longest, rp[r + 1] - rp[r]);
-      if (RB <= 250 && longest <= 65535) {
-        // class-sorted batches of 4 rows per block
-        const int stride = (RB + 3) / 4 + kVibMaxClass + 2;
-        std::vector<uint64_t> tab((size_t)nb * stride * 4, 0);
-        std::vector<int32_t> cnt(nb, 0);
-        std::vector<std::thread> th2;
-        for (int t = 0; t < T; ++t)
-          th2.emplace_back([&, t]() {
-            std::vector<int> ids[kVibMaxClass + 2];
-            for (int64_t b = nb * t / T; b < nb * (t + 1) / T; ++b) {
-              const int64_t r0 = b * RB, r1 = std::min<int64_t>(r0 + RB, m.nrows);
-              for (auto &v : ids) v.clear();
-              for (int64_t r = r0; r < r1; ++r) {
-                const int64_t len = rp[r + 1] - rp[r];
-                const int64_t cls = (len + 63) / 64;
-                ids[cls > kVibMaxClass ? kVibMaxClass + 1 : cls].push_back((int)(r - r0));
-              }
-              int nbt = 0;
-              for (int cls = 0; cls <= kVibMaxClass + 1; ++cls)
-                for (size_t q = 0; q < ids[cls].size(); q += 4) {
-                  uint64_t *dst = &tab[((size_t)b * stride + nbt++) * 4];
-                  for (int i = 0; i < 4; ++i) {
-                    const bool real = q + i < ids[cls].size();
-                    const int id = ids[cls][real ? q + i : q];  // filler: repeat the batch's first row
-                    const uint64_t ks = (uint64_t)(rp[r0 + id] - rp[r0]);
-                    const uint64_t len = (uint64_t)(rp[r0 + id + 1] - rp[r0 + id]);
-                    dst[i] = ks | (len << 32) | ((uint64_t)(real ? id : 0xff) << 48) | ((uint64_t)cls << 56);
-                  }
-                }
-              cnt[b] = nbt;
-            }
-          });
-        for (auto &x : th2) x.join();
-        RC(csr_alloc(ctx, m, &m.vib_tab, (int64_t)tab.size()));
-        RC(csr_alloc(ctx, m, &m.vib_cnt, nb));
-        HIPC(hipMemcpyAsync(m.vib_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPC(hipMemcpyAsync(m.vib_cnt, cnt.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPC(hipStreamSynchronize(ctx->stream));
-        m.vib_stride = stride;
-      }
-      m.vi = true;
-      if (ctx->cfg.log_level > 0)
-        std::fprintf(stderr, "[alfd] value-indexed %s matrix: %lld rows, %lld of %lld blocks coded, dict %zu\n",
-                     slot_is_user ? "user" : "level", (long long)m.nrows, (long long)nvb, (long long)nb, dict.size());
-      m.vi_blocks = nvb;
-      m.vi_nnz = nvn;
-      m.vi_dict_total = (int64_t)dict.size();
-    }
+  if (!pl.vi) return ALFD_OK;
+  RC(upload_vec(ctx, m, &m.vidx, pl.vidx));
+  if (pl.wide_nnz > 0) RC(upload_vec(ctx, m, &m.vidw, pl.vidw));
+  RC(upload_vec(ctx, m, &m.blk_dict_off, pl.doff));
+  RC(upload_vec(ctx, m, &m.blk_dict_n, pl.blk_dn));
+  RC(upload_vec(ctx, m, &m.dict, pl.dict));
+  if (pl.stride > 0) {
+    RC(upload_vec(ctx, m, &m.vib_tab, pl.tab));
+    RC(upload_vec(ctx, m, &m.vib_cnt, pl.cnt));
+    m.vib_stride = pl.stride;
   }
+  HIPC(hipStreamSynchronize(ctx->stream));
+  m.vi = true;
+  m.vi_blocks = pl.vi_blocks;
+  m.vi_nnz = pl.vi_nnz;
+  m.vi_wide_nnz = pl.wide_nnz;
+  m.vi_dict_total = (int64_t)pl.dict.size();
+  if (ctx->cfg.log_level > 0)
+    std::fprintf(stderr, "[alfd] value-indexed %s matrix: %lld rows, %lld of %lld blocks coded, dict %zu\n",
+                 slot_is_user ? "user" : "level", (long long)m.nrows, (long long)pl.vi_blocks, (long long)pl.nb,
+                 pl.dict.size());
   return ALFD_OK;
 }
 
@@ -1679,7 +1710,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
   // enough row blocks to fill the chip (256 CUs x several workgroups)
   const bool win_long = m.L == 64 && m.nrows >= (int64_t)ctx->win_RB * 2048;
   const bool win_short = ctx->win_short_scale > 0 && m.L >= 8 && m.L < 64 &&
-                         m.nrows >= (int64_t)short_row_block(ctx, m.L) * 1024;
+                         m.nrows >= (int64_t)std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / m.L) * 1024;
   if (ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0)
     RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot));
   m.present = true;
@@ -2849,6 +2880,83 @@ int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value
   ctx->vi_off = false;
   if (streamed_bytes) *streamed_bytes = ctx->mat[slot].streamed_bytes(use_value_index != 0);
   return rc;
+}
+
+int alfd_host_window_plan(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int32_t lanes,
+                          int32_t want_value_index, alfd_window_plan_info *out) {
+  if (nrows < 0 || !rp || !out || (rp[nrows] > 0 && (!col || !val))) return ALFD_E_INVALID;
+  if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return ALFD_E_INVALID;
+  WindowParams wp;
+  wp.want_vi = want_value_index != 0;
+  WindowPlan pl;
+  plan_window(nrows, lanes, rp, col, val, wp, pl);
+  std::memset(out, 0, sizeof(*out));
+  out->windowed = pl.win;
+  out->value_indexed = pl.vi;
+  out->row_block = pl.RB;
+  out->max_window = pl.maxW;
+  out->blocks = pl.nb;
+  out->fallback_blocks = pl.fallback;
+  out->segments = (int64_t)pl.seg_col.size();
+  out->value_indexed_blocks = pl.vi ? pl.vi_blocks : 0;
+  out->value_indexed_nnz = pl.vi ? pl.vi_nnz : 0;
+  out->value_wide_nnz = pl.vi ? pl.wide_nnz : 0;
+  out->dictionary_entries = pl.vi ? (int64_t)pl.dict.size() : 0;
+  if (!pl.win) return ALFD_OK;
+  // decode the plan back and compare with the CSR it was made from
+  int64_t bad = 0, batches = 0;
+  std::vector<int32_t> wcol;
+  std::vector<int> seen;
+  for (int64_t b = 0; b < pl.nb; ++b) {
+    const int64_t r0 = b * pl.RB, r1 = std::min<int64_t>(r0 + pl.RB, nrows);
+    const int64_t k0 = rp[r0], k1 = rp[r1];
+    const int32_t W = pl.blkW[b];
+    if (W >= 0) {
+      wcol.assign(W, -1);
+      for (int32_t sg = pl.seg_begin[b]; sg < pl.seg_begin[b + 1]; ++sg) {
+        const int32_t end = (sg + 1 < pl.seg_begin[b + 1]) ? pl.seg_off[sg + 1] : W;
+        for (int32_t o = pl.seg_off[sg]; o < end; ++o) wcol[o] = pl.seg_col[sg] + (o - pl.seg_off[sg]);
+      }
+      for (int64_t k = k0; k < k1; ++k) bad += pl.lcol[k] >= W || wcol[pl.lcol[k]] != col[k];
+    }
+    if (pl.vi && W >= 0 && pl.blk_dn[b] >= 0) {
+      const bool wide = (pl.blk_dn[b] & kDictWide) != 0;
+      const int32_t nd = pl.blk_dn[b] & 0xffff;
+      for (int64_t k = k0; k < k1; ++k) {
+        const int32_t code = wide ? (int32_t)pl.vidw[k] : (int32_t)pl.vidx[k];
+        if (code >= nd || std::memcmp(&pl.dict[pl.doff[b] + code], &val[k], 8) != 0) ++bad;
+      }
+    }
+    if (pl.stride > 0) {
+      seen.assign(r1 - r0, 0);
+      batches += pl.cnt[b];
+      for (int32_t q = 0; q < pl.cnt[b]; ++q) {
+        const uint64_t *dsc = &pl.tab[((size_t)b * pl.stride + q) * 4];
+        const int cls = (int)(dsc[0] >> 56);
+        for (int i = 0; i < 4; ++i) {
+          const int id = (int)((dsc[i] >> 48) & 0xff);
+          const int64_t ks = (int64_t)(dsc[i] & 0xffffffffull), len = (int64_t)((dsc[i] >> 32) & 0xffff);
+          if ((int)(dsc[i] >> 56) != cls) ++bad;
+          if (id == 0xff) {  // filler repeats the batch's first row
+            bad += ks != (int64_t)(dsc[0] & 0xffffffffull) || i == 0;
+            continue;
+          }
+          if (id >= r1 - r0) {
+            ++bad;
+            continue;
+          }
+          ++seen[id];
+          const int64_t rl = rp[r0 + id + 1] - rp[r0 + id];
+          const int64_t want_cls = std::min<int64_t>((rl + 63) / 64, kVibMaxClass + 1);
+          bad += ks != rp[r0 + id] - k0 || len != rl || cls != want_cls;
+        }
+      }
+      for (int v : seen) bad += v != 1;
+    }
+  }
+  out->batches = batches;
+  out->decode_mismatches = bad;
+  return ALFD_OK;
 }
 
 int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan", "alfd_local_group_create",
     "alfd_local_group_destroy", "alfd_comm_init_local", "alfd_set_aggregates",
     "alfd_set_aggregate_partition", "alfd_get_matrix_info", "alfd_bench_spmv_format",
+    "alfd_host_window_plan",
 ]
 
 
@@ -92,6 +93,7 @@ def load_library():
         "alfd_set_aggregate_partition": (C.c_int, [vp, C.c_int, vp]),
         "alfd_get_matrix_info": (C.c_int, [vp, C.c_int, C.POINTER(_abi.MatrixInfo)]),
         "alfd_bench_spmv_format": (C.c_int, [vp, C.c_int, i32, C.c_int, C.POINTER(dbl), C.POINTER(dbl)]),
+        "alfd_host_window_plan": (C.c_int, [i64, vp, vp, vp, i32, i32, C.POINTER(_abi.WindowPlanInfo)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -322,6 +324,21 @@ def host_halo_plan(col, col_offsets, rank):
     if rc != _abi.OK:
         raise AlfdError(rc, "alfd_host_halo_plan failed")
     return col_local, halo[:n_halo.value].copy(), recv_off
+
+
+def host_window_plan(m, lanes=64, value_index=True):
+    """Host-only plan of the LDS-window / value-indexed storage of a problems.Csr (no GPU);
+    returns the alfd_window_plan_info fields, incl. decode_mismatches (0 for a correct plan)."""
+    lib = load_library()
+    rp = np.ascontiguousarray(m.row_ptr, np.int64)
+    col = np.ascontiguousarray(m.col, np.int32)
+    val = np.ascontiguousarray(m.val, np.float64)
+    info = _abi.WindowPlanInfo()
+    rc = lib.alfd_host_window_plan(m.nrows, rp.ctypes.data, col.ctypes.data, val.ctypes.data, lanes,
+                                   int(value_index), C.byref(info))
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_window_plan failed")
+    return {k: getattr(info, k) for k, _ in info._fields_}
 
 
 def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None) -> Context:

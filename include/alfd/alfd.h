@@ -306,6 +306,20 @@ typedef struct alfd_matrix_info {
   double algorithmic_bytes, streamed_bytes;
 } alfd_matrix_info;
 int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out);
+/* Host-only (no device, no context): plans the LDS-window / value-indexed storage of
+ * a CSR matrix exactly as alfd_set_matrix would (default tunables), decodes the plan
+ * back -- window columns through the segment table, values through the block
+ * dictionaries, every row through the class-sorted batch descriptors -- and reports
+ * the number of entries / rows that do not reproduce the input (must be 0).
+ * lanes: the canonical lanes-per-row of the matrix (alfd_matrix_lanes). */
+typedef struct alfd_window_plan_info {
+  int32_t windowed, value_indexed, row_block, max_window;
+  int64_t blocks, fallback_blocks, segments;
+  int64_t value_indexed_blocks, value_indexed_nnz, value_wide_nnz, dictionary_entries;
+  int64_t batches, decode_mismatches;
+} alfd_window_plan_info;
+int alfd_host_window_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                          int32_t lanes, int32_t want_value_index, alfd_window_plan_info *out);
 /* alfd_bench_spmv with the value-indexed kernel switched on (1) or off (0: the same
  * matrix through the 10 B/nnz window kernel); streamed_bytes as in alfd_matrix_info. */
 int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value_index,

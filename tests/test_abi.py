@@ -46,7 +46,7 @@ def test_version_strerror_and_default_config_mirror():
     assert (c.restart, c.inner.max_steps, c.inner.tol, c.inner.kind) == (30, 100, 1e-2, _abi.CTRL_ABS)
     assert _abi.default_config(_abi.AL_ELL_MODIFIED).restart == 50
     assert C.sizeof(_abi.Config) == 216 and C.sizeof(_abi.Result) == 72
-    assert C.sizeof(_abi.MatrixInfo) == 88
+    assert C.sizeof(_abi.MatrixInfo) == 88 and C.sizeof(_abi.WindowPlanInfo) == 88
 
 
 def test_argument_validation_without_gpu():
@@ -77,3 +77,53 @@ def test_product_package_never_imports_the_oracle():
                 # no import, dlopen, include or path of anything under oracle/
                 hits = re.findall(r"(import\s+oracle|from\s+oracle|liboracle|oracle/|orc_[a-z_]+\s*\()", txt)
                 assert not hits, (os.path.join(dirpath, f), hits)
+
+
+def test_host_window_plan_decodes_back():
+    """The LDS-window / value-indexed storage planned on the host (what alfd_set_matrix uploads)
+    decodes back to the CSR it was made from: window columns, dictionary values (8-bit, 16-bit,
+    raw blocks) and the class-sorted row batches -- no GPU involved."""
+    import numpy as np
+    from fictitious_domain_al_preconditioners_amd import problems
+    pb = problems.generate(dim=3, degree=2, ncomp=3, n_cells=6, stokes=False, grad_div=True,
+                           gamma_grad_div=10.0, radius=0.1, immersed_refine=0)
+    a = pb.mats["A"]                                         # 6591 rows, long rows, few distinct values
+    info = solver.host_window_plan(a, 64, True)
+    assert info["windowed"] and info["value_indexed"] and info["decode_mismatches"] == 0
+    assert info["row_block"] == 96 and info["blocks"] == -(-a.nrows // 96)
+    assert info["value_indexed_nnz"] == a.nnz and info["value_wide_nnz"] == 0 and info["batches"] > 0
+    assert info["dictionary_entries"] <= 256 * info["blocks"]
+    rng = np.random.default_rng(3)
+    # 16-bit codes: every value scaled by one of 9 factors
+    v = np.array(a.val) * (1.0 + 0.125 * rng.integers(0, 9, a.nnz))
+    wide = problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), v)
+    info = solver.host_window_plan(wide, 64, True)
+    assert info["value_indexed"] and info["value_wide_nnz"] > 0 and info["decode_mismatches"] == 0
+    # raw blocks in the first third of the rows
+    v = np.array(a.val)
+    cut = int(a.row_ptr[a.nrows // 3])
+    v[:cut] = rng.uniform(-1, 1, cut)
+    raw = problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), v)
+    info = solver.host_window_plan(raw, 64, True)
+    assert info["value_indexed"] and 0 < info["value_indexed_blocks"] < info["blocks"]
+    assert info["decode_mismatches"] == 0
+    # no dictionary requested / random values: plain window format
+    info = solver.host_window_plan(a, 64, False)
+    assert info["windowed"] and not info["value_indexed"] and info["decode_mismatches"] == 0
+    # short rows (27-point stencil, 32 lanes): window format with larger row blocks
+    q1 = problems.generate(dim=3, degree=1, ncomp=1, n_cells=20, radius=0.1).mats["A"]
+    info = solver.host_window_plan(q1, 32, True)
+    assert info["windowed"] and not info["value_indexed"] and info["row_block"] == 384
+    assert info["decode_mismatches"] == 0
+    # ragged rows, empty rows and far-away columns: some blocks fall back, the rest still decode
+    import scipy.sparse as sp
+    n = 20000
+    cnt = rng.integers(0, 200, n)
+    rows = np.repeat(np.arange(n), cnt)
+    cols = np.clip(rows + rng.integers(-300, 301, rows.size), 0, n - 1)
+    far = rng.integers(0, rows.size, 50)
+    cols[far] = rng.integers(0, n, 50)
+    m = sp.csr_matrix((rng.integers(1, 6, rows.size).astype(float), (rows, cols)), shape=(n, n))
+    m.sum_duplicates()
+    info = solver.host_window_plan(problems.Csr.from_scipy(m), 64, True)
+    assert info["decode_mismatches"] == 0 and info["blocks"] == -(-n // 96)
