@@ -23,6 +23,8 @@ PREC_IDENTITY, PREC_JACOBI, PREC_CHEBYSHEV, PREC_MULTILEVEL = range(4)
 ORTH_MGS, ORTH_CGS, ORTH_CGS2 = range(3)
 # enum alfd_outer_solver
 OUTER_FGMRES, OUTER_MINRES = range(2)
+# enum alfd_w_inverse
+W_DIAGONAL, W_MASS_INV_SQUARED, W_MASS_INV = range(3)
 # enum alfd_inner_failure_policy
 INNER_THROW, INNER_ACCEPT = range(2)
 # enum alfd_timing_class
@@ -51,7 +53,8 @@ class Config(C.Structure):
         ("rho_bound", C.c_double), ("rational", Control),
         ("ml_smooth_degree", C.c_int32), ("ml_coarse_degree", C.c_int32),
         ("ml_smooth_ratio", C.c_double), ("ml_coarse_ratio", C.c_double),
-        ("aug_assembled", C.c_int32), ("reserved", C.c_int32),
+        ("aug_assembled", C.c_int32), ("w_inverse", C.c_int32),
+        ("mass", Control),
     ]
 
 
@@ -62,7 +65,7 @@ class Result(C.Structure):
         ("inner_iterations", C.c_int64), ("mp_iterations", C.c_int64),
         ("inner_failures", C.c_int32), ("precond_applications", C.c_int32),
         ("solve_seconds", C.c_double), ("lambda_max", C.c_double),
-        ("rational_iterations", C.c_int64),
+        ("rational_iterations", C.c_int64), ("mass_iterations", C.c_int64),
     ]
 
     def as_dict(self):
@@ -112,4 +115,6 @@ def default_config(variant=AL_STOKES) -> Config:
     c.rational = Control(CTRL_ABS, 2000, 1e-14, 0.0)      # rational_preconditioner.h:34
     c.ml_smooth_degree, c.ml_coarse_degree = 3, 40
     c.ml_smooth_ratio, c.ml_coarse_ratio = 4.0, 400.0
+    c.w_inverse = W_DIAGONAL
+    c.mass = Control(CTRL_REDUCTION, 1000, 1e-30, 1e-14)
     return c

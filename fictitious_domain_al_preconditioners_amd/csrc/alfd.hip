@@ -183,8 +183,14 @@ struct alfd_ctx {
   double *gather = nullptr;    // multi-rank scalar all-gather buffer
   double *dinv_aug = nullptr, *dA = nullptr, *s_aug = nullptr;
   double *dinv_a22 = nullptr, *dinv_aug2 = nullptr;   // elliptic: 1/diag(A22_aug), [dinv_aug | dinv_a22]
-  double lam_max[6] = {0, 0, 0, 0, 0, 0};              // per inner operator kind
+  double lam_max[7] = {0, 0, 0, 0, 0, 0, 0};              // per inner operator kind
   double *dinv_k = nullptr;                            // rational: 1/diag(K)
+  // exact W^-1 (alfd_config::w_inverse != 0): Jacobi CG on M nested inside the operator the
+  // outer inner-CG runs on, so it owns a second set of CG vectors / scalar tables
+  double *dinv_m = nullptr, *m_tmp = nullptr, *m_tmp2 = nullptr;
+  double *n_r = nullptr, *n_z = nullptr, *n_p = nullptr, *n_Ap = nullptr;
+  double *n_sc = nullptr, *n_sc_host = nullptr, *n_partial = nullptr, *n_gather = nullptr;
+  int64_t mass_its = 0;
   // RationalPreconditioner state (batched CG over the 21 immersed systems)
   HostCsr h_M, h_K;                                    // host copies of the (tiny) immersed matrices
   // multilevel inner preconditioner
@@ -670,20 +676,33 @@ static int read_scalars(alfd_ctx *ctx, int first, int count) {
 //            s = C x0 - M x1, t = invW .* s, y0 = A x0 + gamma Ct t, y1 = A2 x1 - gamma2 M t
 //   OP_K     y = A x  (K_inv of the rational branch: UMFPACK in the reference,
 //            immersed_laplace.cc:617-620; here CG to alfd_config::inner)
-enum OpKind { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3, OP_K = 4 };
+//   OP_MASS  y = M x  (the immersed mass matrix of the exact W^-1 = (M^-1)^2, stokes...:979-985)
+enum OpKind { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3, OP_K = 4, OP_MASS = 5 };
 
 static inline int64_t op_npad(const alfd_ctx *ctx, int op) {
+  if (op == OP_MASS) return pad_chunk(ctx->n[ctx->nblocks - 1]);
   return (op == OP_AUG || op == OP_K) ? pad_chunk(ctx->n[0]) : op == OP_AUG2 ? ctx->off[2] : pad_chunk(ctx->n[1]);
 }
 
-static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y) {
+static int winv_scale(alfd_ctx *ctx, double alpha, const double *src, double *dst);
+
+// exact_w: apply the configured W^-1 (the operator the inner CG and the outer system see);
+// false: the diagonal weight (everything inside the inner preconditioner).
+static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y, bool exact_w = false) {
   const double *w = ctx->diag[ALFD_INVW];
   switch (op) {
     case OP_AUG:
       RC(spmv(ctx, ALFD_A, x, y, 0));
       if (ctx->cfg.aug_assembled) return ALFD_OK;  // operator form: A already holds the AL term
-      RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 2, 0.0, w));
+      if (exact_w && ctx->cfg.w_inverse != ALFD_W_DIAGONAL) {
+        RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 0));
+        RC(winv_scale(ctx, 1.0, ctx->t_lam, ctx->t_lam));
+      } else {
+        RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 2, 0.0, w));
+      }
       return spmv(ctx, ALFD_CT, ctx->t_lam, y, 1, ctx->cfg.gamma);
+    case OP_MASS:
+      return spmv(ctx, ALFD_M, x, y, 0);
     case OP_MP:
       return spmv(ctx, ALFD_MP, x, y, 0);
     case OP_K:
@@ -709,7 +728,7 @@ static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y) {
 
 static const double *op_dinv(const alfd_ctx *ctx, int op) {
   return op == OP_AUG ? ctx->dinv_aug : op == OP_A22 ? ctx->dinv_a22 : op == OP_AUG2 ? ctx->dinv_aug2
-         : op == OP_K ? ctx->dinv_k : ctx->diag[ALFD_MP_LUMPED_INV];
+         : op == OP_K ? ctx->dinv_k : op == OP_MASS ? ctx->dinv_m : ctx->diag[ALFD_MP_LUMPED_INV];
 }
 
 // Chebyshev sweep z = p_k(D^-1 Op) D^-1 r
@@ -772,7 +791,7 @@ static int pcg(alfd_ctx *ctx, int op, int prec, const alfd_control &ctrl, const 
       RC(dot_async(ctx, npad, r, z, 0, FIN_RZ));
     }
     VEC_LAUNCH(p_update_kernel, npad, its == 1 ? 16 : 24, ctx->sc, its == 1 ? 1 : 0, zz, p);
-    RC(op_apply(ctx, op, p, Ap));
+    RC(op_apply(ctx, op, p, Ap, true));
     RC(dot_async(ctx, npad, p, Ap, 0, FIN_ALPHA));
     VEC_LAUNCH(xr_update_dot_kernel, npad, 48, ctx->sc, p, Ap, x, r, ctx->partial);
     RC(finish_dots(ctx, nb, 1, S_RR, FIN_STORE));
@@ -808,6 +827,52 @@ static int inner_solve(alfd_ctx *ctx, int op, const double *b, double *x) {
 }
 
 static inline bool is_elliptic(int v) { return v == ALFD_AL_ELL_IDEAL || v == ALFD_AL_ELL_MODIFIED; }
+
+// x = M^-1 b by Jacobi-preconditioned CG to alfd_config::mass (UMFPACK in the reference,
+// stokes...:966-968).  It may run in the middle of an outer inner-CG iteration (inside
+// Aug p), so it works on its own CG vectors, scalar table and reduction buffers.
+static int mass_solve(alfd_ctx *ctx, const double *b, double *x) {
+  auto swap_ws = [&]() {
+    std::swap(ctx->w_r, ctx->n_r);
+    std::swap(ctx->w_z, ctx->n_z);
+    std::swap(ctx->w_p, ctx->n_p);
+    std::swap(ctx->w_Ap, ctx->n_Ap);
+    std::swap(ctx->sc, ctx->n_sc);
+    std::swap(ctx->sc_host, ctx->n_sc_host);
+    std::swap(ctx->partial, ctx->n_partial);
+    std::swap(ctx->gather, ctx->n_gather);
+  };
+  int its = 0;
+  State st = FAILURE;
+  double res = 0;
+  swap_ws();
+  const int rc = pcg(ctx, OP_MASS, ALFD_PREC_JACOBI, ctx->cfg.mass, b, x, &its, &st, &res);
+  swap_ws();
+  if (rc != ALFD_OK) return rc;
+  ctx->mass_its += its;
+  if (st == FAILURE) {
+    if (std::isnan(res)) return ctx->err = "mass-matrix CG breakdown (NaN)", ALFD_E_BREAKDOWN;
+    return ctx->err = "mass-matrix CG (exact W^-1) did not converge", ALFD_E_NO_CONVERGENCE_INNER;
+  }
+  return ALFD_OK;
+}
+
+// dst = alpha * W^-1 src on the multiplier block (padded vectors; dst may alias src)
+static int winv_scale(alfd_ctx *ctx, double alpha, const double *src, double *dst) {
+  const int64_t nlp = pad_chunk(ctx->n[ctx->nblocks - 1]);
+  if (ctx->cfg.w_inverse == ALFD_W_DIAGONAL) {
+    VEC_LAUNCH(pmul_scale_kernel, nlp, 24, alpha, ctx->diag[ALFD_INVW], src, dst);
+    return ALFD_OK;
+  }
+  RC(mass_solve(ctx, src, ctx->m_tmp));
+  const double *z = ctx->m_tmp;
+  if (ctx->cfg.w_inverse == ALFD_W_MASS_INV_SQUARED) {
+    RC(mass_solve(ctx, ctx->m_tmp, ctx->m_tmp2));
+    z = ctx->m_tmp2;
+  }
+  VEC_LAUNCH(scale_copy_kernel, nlp, 16, alpha, z, dst);
+  return ALFD_OK;
+}
 
 // ---- RationalPreconditioner (rational_preconditioner.h:29-63) ----------------
 static const double kRatRes[21] = {
@@ -927,7 +992,7 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
   const int64_t n0p = pad_chunk(ctx->n[0]), n1p = pad_chunk(ctx->n[1]), n2p = pad_chunk(ctx->n[2]);
   if (c.variant == ALFD_AL2) {
     // augmented_lagrangian_preconditioner.h:28-34
-    VEC_LAUNCH(pmul_scale_kernel, n1p, 24, -c.gamma, w, u + off[1], v + off[1]);
+    RC(winv_scale(ctx, -c.gamma, u + off[1], v + off[1]));
     HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
                         ctx->stream));
     RC(spmv(ctx, ALFD_CT, v + off[1], ctx->rhs_tmp, 1, -1.0));
@@ -937,7 +1002,7 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
     // :62-70 (block triangular) / :95-103 (block diagonal SPD)
     const bool tri = c.variant == ALFD_AL_STOKES;
     const double sgn = tri ? -1.0 : 1.0;
-    VEC_LAUNCH(pmul_scale_kernel, n2p, 24, sgn * c.gamma, w, u + off[2], v + off[2]);
+    RC(winv_scale(ctx, sgn * c.gamma, u + off[2], v + off[2]));
     RC(inner_solve(ctx, OP_MP, u + off[1], ctx->q_tmp));
     VEC_LAUNCH(scale_copy_kernel, n1p, 16, sgn * c.gamma_grad_div, ctx->q_tmp, v + off[1]);
     HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
@@ -991,7 +1056,12 @@ static int system_apply(alfd_ctx *ctx, const double *x, double *y) {
     if (c.aug_assembled) {
       RC(spmv(ctx, ALFD_C, x0, y + off[last], 0));
     } else {
-      RC(spmv(ctx, ALFD_C, x0, y + off[last], 3, 0.0, w, ctx->t_lam));
+      if (c.w_inverse != ALFD_W_DIAGONAL) {
+        RC(spmv(ctx, ALFD_C, x0, y + off[last], 0));
+        RC(winv_scale(ctx, 1.0, y + off[last], ctx->t_lam));
+      } else {
+        RC(spmv(ctx, ALFD_C, x0, y + off[last], 3, 0.0, w, ctx->t_lam));
+      }
       RC(spmv(ctx, ALFD_CT, ctx->t_lam, y0, 1, c.gamma));
     }
     if (ctx->nblocks == 3) {
@@ -2254,7 +2324,41 @@ static int setup(alfd_ctx *ctx) {
   RC(ws_alloc_zero(ctx, &ctx->xb, N));
   RC(ws_alloc_zero(ctx, &ctx->bb, N));
   RC(ws_alloc_zero(ctx, &ctx->io, N));
-  for (int k = 0; k < 6; ++k) ctx->lam_max[k] = 0;
+  for (int k = 0; k < 7; ++k) ctx->lam_max[k] = 0;
+  if (ctx->n_sc_host) hipHostFree(ctx->n_sc_host), ctx->n_sc_host = nullptr;
+  if (c.w_inverse != ALFD_W_DIAGONAL) {
+    // exact W^-1 = (M^-1)^2 or M^-1: nested Jacobi CG on the immersed mass matrix
+    if (c.w_inverse != ALFD_W_MASS_INV_SQUARED && c.w_inverse != ALFD_W_MASS_INV)
+      return ctx->err = "unknown alfd_config::w_inverse", ALFD_E_INVALID;
+    if (rat || ell)
+      return ctx->err = "exact W^-1 is implemented for the AL2 and Stokes variants", ALFD_E_UNSUPPORTED;
+    const HostCsr &M = ctx->h_M;
+    if (!ctx->mat[ALFD_M].present || M.rp.empty() || M.nrows != ctx->n[last])
+      return ctx->err = "slot M (immersed mass matrix) must be set for the exact W^-1", ALFD_E_NOT_SETUP;
+    const int64_t nlp = pad_chunk(ctx->n[last]);
+    const int64_t row0 = ctx->nranks > 1 ? ctx->part[last][ctx->rank] : 0;
+    std::vector<double> dm(nlp, 0.0);
+    for (int64_t i = 0; i < M.nrows; ++i) {
+      double dii = 0.0;
+      for (int64_t k = M.rp[i]; k < M.rp[i + 1]; ++k)
+        if (M.col[k] == row0 + i) dii = M.val[k];
+      if (!(dii > 0.0)) return ctx->err = "mass matrix needs a positive diagonal", ALFD_E_INVALID;
+      dm[i] = 1.0 / dii;
+    }
+    RC(ws_alloc_zero(ctx, &ctx->dinv_m, nlp));
+    HIPC(hipMemcpyAsync(ctx->dinv_m, dm.data(), nlp * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    RC(ws_alloc_zero(ctx, &ctx->m_tmp, nlp));
+    RC(ws_alloc_zero(ctx, &ctx->m_tmp2, nlp));
+    RC(ws_alloc_zero(ctx, &ctx->n_r, nlp));
+    RC(ws_alloc_zero(ctx, &ctx->n_z, nlp));
+    RC(ws_alloc_zero(ctx, &ctx->n_p, nlp));
+    RC(ws_alloc_zero(ctx, &ctx->n_Ap, nlp));
+    RC(ws_alloc_zero(ctx, &ctx->n_sc, kNumScalars));
+    HIPC(hipHostMalloc((void **)&ctx->n_sc_host, kNumScalars * sizeof(double), hipHostMallocMapped));
+    RC(ws_alloc_zero(ctx, &ctx->n_partial, (int64_t)(kMaxBasis + 2) * ctx->pstride));
+    RC(ws_alloc_zero(ctx, &ctx->n_gather, (int64_t)ctx->nranks * (kMaxBasis + 2)));
+  }
   const bool cheb = c.inner_prec == ALFD_PREC_CHEBYSHEV || c.inner_prec == ALFD_PREC_MULTILEVEL;
   if (rat) {
     // K_inv: Jacobi / Chebyshev-Jacobi CG on K itself
@@ -2395,6 +2499,7 @@ static void reset_stats(alfd_ctx *ctx) {
   ctx->inner_its = ctx->mp_its = 0;
   ctx->inner_failures = ctx->precond_applications = 0;
   ctx->rational_its = 0;
+  ctx->mass_its = 0;
 }
 static void fill_result(alfd_ctx *ctx, alfd_result *res, int status) {
   res->status = status;
@@ -2404,6 +2509,7 @@ static void fill_result(alfd_ctx *ctx, alfd_result *res, int status) {
   res->precond_applications = ctx->precond_applications;
   res->lambda_max = ctx->lambda_max;
   res->rational_iterations = ctx->rational_its;
+  res->mass_iterations = ctx->mass_its;
 }
 
 }  // namespace alfd
@@ -2484,6 +2590,7 @@ int alfd_destroy(alfd_ctx_t ctx) {
   for (void *p : ctx->ws_allocs) hipFree(p);
   for (void *p : ctx->allocs) hipFree(p);
   if (ctx->sc_host) hipHostFree(ctx->sc_host);
+  if (ctx->n_sc_host) hipHostFree(ctx->n_sc_host);
   if (ctx->rt_scb_host) hipHostFree(ctx->rt_scb_host);
   if (ctx->nccl) ncclCommDestroy(ctx->nccl);
   hipStreamDestroy(ctx->stream);
@@ -2631,6 +2738,8 @@ void alfd_default_config(alfd_config *c, int variant) {
   c->ml_coarse_degree = 40;
   c->ml_smooth_ratio = 4.0;
   c->ml_coarse_ratio = 400.0;
+  c->w_inverse = ALFD_W_DIAGONAL;
+  c->mass = {ALFD_CTRL_REDUCTION, 1000, 1e-30, 1e-14};
 }
 
 int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t *agg, const double *weight,
@@ -2707,8 +2816,7 @@ int alfd_augment_rhs(alfd_ctx_t ctx, double *const *rhs) {
     return ctx->err = "rhs augmentation applies to the AL variants only", ALFD_E_UNSUPPORTED;
   const int last = ctx->nblocks - 1;
   RC(to_device(ctx, rhs, ctx->bb));
-  VEC_LAUNCH(pmul_scale_kernel, pad_chunk(ctx->n[last]), 24, 1.0, ctx->diag[ALFD_INVW],
-             ctx->bb + ctx->off[last], ctx->t_lam);
+  RC(winv_scale(ctx, 1.0, ctx->bb + ctx->off[last], ctx->t_lam));
   RC(spmv(ctx, ALFD_CT, ctx->t_lam, ctx->bb + ctx->off[0], 1, ctx->cfg.gamma));
   return to_host(ctx, ctx->bb, rhs);
 }

@@ -101,7 +101,8 @@ def config_from_prm(tree: dict) -> tuple[_abi.Config, dict]:
         if info["solver"] != "IBStokesAL":
             info["unsupported"].append(f"Solver = {info['solver']} (non-AL branch, out of scope)")
         if not info["diagonal_W"]:
-            info["unsupported"].append("Diagonal mass immersed = false (UMFPACK W^-1, SURVEY 8(f) rank 4)")
+            # stokes...:979-985: invW = M^-1 M^-1 (UMFPACK there, CG on slot M here)
+            cfg.w_inverse = _abi.W_MASS_INV_SQUARED
         if not cfg.grad_div_in_A:
             info["unsupported"].append("Grad-div stabilization = false (nested Bt Mp^-1 B in Aug)")
         if spd:
@@ -127,7 +128,9 @@ def config_from_prm(tree: dict) -> tuple[_abi.Config, dict]:
             cfg.aug_assembled = 1
             info["gamma_needs_h_scaling"] = True
         if not info["diagonal_W"]:
-            info["unsupported"].append("Use diagonal inverse = false (UMFPACK (M^-1)^2)")
+            # immersed_laplace.cc:859-877: M^-1 in operator form, (M^-1)^2 otherwise (UMFPACK there,
+            # CG on the immersed mass matrix here -- the caller uploads slot M)
+            cfg.w_inverse = _abi.W_MASS_INV if info["use_operator_form"] else _abi.W_MASS_INV_SQUARED
         return cfg, info
     if ell is not None:
         info["driver"] = "elliptic_interface"

@@ -369,6 +369,8 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None) -> Conte
         ctx.configure(cfg)
         ctx.setup(pb.block_sizes)
         return ctx
+    if cfg.w_inverse != _abi.W_DIAGONAL:
+        ctx.set_matrix(_abi.M, pb.mats["M"])     # exact W^-1: CG on the immersed mass matrix
     ctx.set_diag(_abi.INVW, pb.inv_w_diag_squared())
     if "B" in pb.mats:
         ctx.set_matrix(_abi.BT, pb.mats["Bt"])

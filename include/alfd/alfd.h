@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 5
+#define ALFD_ABI_VERSION 6
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -133,6 +133,16 @@ enum alfd_outer_solver { ALFD_OUTER_FGMRES = 0, ALFD_OUTER_MINRES = 1 };
  * SolverControl::NoConvergence (THROW); ACCEPT keeps the last iterate. */
 enum alfd_inner_failure_policy { ALFD_INNER_THROW = 0, ALFD_INNER_ACCEPT = 1 };
 
+/* The weight W^-1 of the AL term gamma Ct W^-1 C.  DIAGONAL: the caller's vector
+ * (ALFD_INVW: 1/M_ii^2, or 1/M_ii in operator form) -- `Use diagonal inverse = true`.
+ * MASS_INV_SQUARED / MASS_INV: the exact (M^-1)^2 / M^-1 of the reference's
+ * `Use diagonal inverse = false` branch (immersed_laplace.cc:866-877, stokes...:979-985,
+ * UMFPACK there): every application runs Jacobi-preconditioned CG on the immersed mass
+ * matrix (slot ALFD_M) to alfd_config::mass.  The inner preconditioner (Jacobi /
+ * Chebyshev / multilevel) keeps using the diagonal weight, as the reference builds its
+ * AMG from the diagonal form in either case (utilities.h:218-331). */
+enum alfd_w_inverse { ALFD_W_DIAGONAL = 0, ALFD_W_MASS_INV_SQUARED = 1, ALFD_W_MASS_INV = 2 };
+
 typedef struct alfd_config {
   int32_t variant;            /* enum alfd_variant */
   int32_t restart;            /* FGMRES max_basis_size: 30 default, 50 elliptic...:863 */
@@ -164,7 +174,8 @@ typedef struct alfd_config {
    * the caller has assembled the AL term into A (gamma/h * int_Gamma phi_i phi_j), so
    * Aug = A and only the preconditioner and the rhs augmentation use gamma and invW. */
   int32_t aug_assembled;
-  int32_t reserved;
+  int32_t w_inverse;          /* enum alfd_w_inverse */
+  alfd_control mass;          /* CG on M for the exact W^-1: ReductionControl(1000, 1e-30, 1e-14) */
 } alfd_config;
 
 typedef struct alfd_result {
@@ -179,6 +190,7 @@ typedef struct alfd_result {
   double solve_seconds;       /* wall time inside alfd_solve, device-synchronised */
   double lambda_max;          /* Chebyshev: estimated lambda_max(D^-1 Aug) incl. safety */
   int64_t rational_iterations;/* total CG iterations of the 21 immersed solves (ALFD_RATIONAL) */
+  int64_t mass_iterations;    /* total CG iterations on M (exact W^-1 modes) */
 } alfd_result;
 
 typedef struct alfd_ctx *alfd_ctx_t;

@@ -109,7 +109,8 @@ inline double row_sum(const Csr &m, int64_t r, const double *x) {
 
 // mode 0: y = A x ; mode 1: y = fma(alpha, A x, y)
 void spmv(const Csr &m, const double *x, double *y, int mode, double alpha) {
-#pragma omp parallel for schedule(static)
+  // threads only where they pay (results do not depend on the thread count)
+#pragma omp parallel for schedule(static) if (m.nrows > 0 && m.rp[m.nrows] > 32768)
   for (int64_t r = 0; r < m.nrows; ++r) {
     if (mode == 1 && m.rp[r + 1] == m.rp[r]) continue;  // empty row: y unchanged
     const double s = row_sum(m, r, x);
@@ -132,7 +133,7 @@ double dot(int64_t n, const double *x, const double *y) {
   if (n <= 0) return 0.0;
   const int64_t nb = (n + CHUNK - 1) / CHUNK;
   std::vector<double> part(nb);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (nb > 8)
   for (int64_t b = 0; b < nb; ++b) {
     double lane[256];
     const int64_t base = b * CHUNK;
@@ -158,27 +159,27 @@ double dot(int64_t n, const double *x, const double *y) {
 
 // ---- elementwise (padding entries are zero and stay zero)
 inline void axpy(int64_t n, double a, const double *x, double *y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 32768)
   for (int64_t i = 0; i < n; ++i) y[i] = std::fma(a, x[i], y[i]);
 }
 inline void xpby(int64_t n, const double *x, double b, double *y) {  // y = x + b y
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 32768)
   for (int64_t i = 0; i < n; ++i) y[i] = std::fma(b, y[i], x[i]);
 }
 inline void scale(int64_t n, double a, double *x) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 32768)
   for (int64_t i = 0; i < n; ++i) x[i] = a * x[i];
 }
 inline void pmul(int64_t n, const double *d, const double *x, double *y) {  // y = d .* x
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 32768)
   for (int64_t i = 0; i < n; ++i) y[i] = d[i] * x[i];
 }
 inline void pmul_scale(int64_t n, double a, const double *d, const double *x, double *y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 32768)
   for (int64_t i = 0; i < n; ++i) y[i] = a * (d[i] * x[i]);  // y = a (d .* x)
 }
 inline void sub_from(int64_t n, const double *b, double *v) {  // v = b - v
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 32768)
   for (int64_t i = 0; i < n; ++i) v[i] = b[i] - v[i];
 }
 
@@ -222,6 +223,7 @@ struct Problem {
   alfd_config cfg;
   // setup products
   std::vector<double> dinv_aug, dinv_a22, dinv_aug2, dinv_k;  // 1/diag of the inner operators
+  std::vector<double> dinv_m;                                 // 1/diag(M): Jacobi of the exact-W^-1 mass solves
   double lam_max[6] = {0, 0, 0, 0, 0, 0};             // per inner operator kind
   std::vector<Csr> shifted;                           // A_Gamma - rho p_i M (rational_preconditioner.h:42-45)
   // aggregation multigrid (ALFD_PREC_MULTILEVEL): inputs + hierarchy
@@ -238,7 +240,8 @@ struct Problem {
   };
   std::vector<Level> ml;
   std::vector<std::vector<double>> shifted_dinv;
-  int64_t rational_its = 0;
+  int64_t rational_its = 0, mass_its = 0;
+  int winv_status = 0;  // first failure of a nested mass solve (ALFD_OK otherwise)
   double lambda_max = 0;
   // stats
   int64_t inner_its = 0, mp_its = 0;
@@ -292,13 +295,24 @@ static void transpose_into(const Csr &a, Csr &t) {
 // kind 5: an explicit matrix on block 1 (the shifted immersed systems / the immersed mass)
 enum { OP_AUG = 0, OP_MP = 1, OP_A22 = 2, OP_AUG2 = 3, OP_K = 4, OP_MAT = 5 };
 
+// dst = alpha * W^-1 src on the multiplier block (defined after pcg)
+static int winv_scale(Problem &P, double alpha, const double *src, double *dst);
+
 struct InnerOp {
   Problem &P;
   int kind;
   std::vector<double> t;
   const Csr *mat = nullptr;
-  int64_t n() const { return (kind == OP_AUG || kind == OP_K) ? P.n[0] : kind == OP_AUG2 ? P.off[2] : P.n[1]; }
-  int blk() const { return (kind == OP_AUG || kind == OP_K) ? 0 : kind == OP_AUG2 ? -1 : 1; }
+  int mat_blk = 1;      // OP_MAT: the block the matrix acts on
+  bool exact_w = false; // apply the configured W^-1 (alfd_config::w_inverse); false: diagonal weight
+  int64_t n() const {
+    if (kind == OP_MAT) return P.n[mat_blk];
+    return (kind == OP_AUG || kind == OP_K) ? P.n[0] : kind == OP_AUG2 ? P.off[2] : P.n[1];
+  }
+  int blk() const {
+    if (kind == OP_MAT) return mat_blk;
+    return (kind == OP_AUG || kind == OP_K) ? 0 : kind == OP_AUG2 ? -1 : 1;
+  }
   void operator()(const double *x, double *y) {
     const double *w = P.diag[ALFD_INVW];
     if (kind == OP_K) {
@@ -312,7 +326,8 @@ struct InnerOp {
       spmv(P.mat[ALFD_A], x, y, 0, 0.0);
       t.resize(C.nrows);
       spmv(C, x, t.data(), 0, 0.0);
-      pmul(C.nrows, w, t.data(), t.data());
+      if (exact_w && P.cfg.w_inverse != ALFD_W_DIAGONAL) winv_scale(P, 1.0, t.data(), t.data());
+      else pmul(C.nrows, w, t.data(), t.data());
       spmv(P.mat[ALFD_CT], t.data(), y, 1, P.cfg.gamma);
     } else if (kind == OP_MP) {
       spmv(P.mat[ALFD_MP], x, y, 0, 0.0);
@@ -444,6 +459,37 @@ static State pcg(const Problem &P, InnerOp &op, Prec &prec, const alfd_control &
   return st;
 }
 
+// Exact W^-1 (immersed_laplace.cc:866-877, stokes...:979-985: UMFPACK M^-1 in the reference):
+// Jacobi-preconditioned CG on the immersed mass matrix to alfd_config::mass, once (M^-1) or
+// twice ((M^-1)^2), then the scalar factor.
+static int winv_scale(Problem &P, double alpha, const double *src, double *dst) {
+  const int last = P.nblocks - 1;
+  const int64_t n = P.n[last];
+  if (P.cfg.w_inverse == ALFD_W_DIAGONAL) {
+    pmul_scale(n, alpha, P.diag[ALFD_INVW], src, dst);
+    return ALFD_OK;
+  }
+  auto mass_solve = [&](const double *b, double *x) {
+    InnerOp op{P, OP_MAT, {}, &P.mat[ALFD_M], last};
+    DiagPrec pr{P.dinv_m.data()};
+    int its = 0;
+    double res = 0;
+    const State st = pcg(P, op, pr, P.cfg.mass, b, x, its, res, 0, "mass");
+    P.mass_its += its;
+    if (st == FAILURE && P.winv_status == ALFD_OK)
+      P.winv_status = std::isnan(res) ? ALFD_E_BREAKDOWN : ALFD_E_NO_CONVERGENCE_INNER;
+  };
+  std::vector<double> z1(n), z2(n);
+  mass_solve(src, z1.data());
+  const double *z = z1.data();
+  if (P.cfg.w_inverse == ALFD_W_MASS_INV_SQUARED) {
+    mass_solve(z1.data(), z2.data());
+    z = z2.data();
+  }
+  for (int64_t i = 0; i < n; ++i) dst[i] = alpha * z[i];
+  return P.winv_status;
+}
+
 // dinv / lambda of the inner operator `kind`
 static const double *op_dinv(const Problem &P, int kind) {
   return kind == OP_AUG ? P.dinv_aug.data() : kind == OP_A22 ? P.dinv_a22.data()
@@ -459,6 +505,7 @@ struct MlPrec {
 
 static int inner_solve(Problem &P, int kind, const double *b, double *x) {
   InnerOp op{P, kind, {}};
+  op.exact_w = true;  // the operator the CG runs on; the preconditioners keep the diagonal weight
   int its = 0;
   double res = 0;
   State st;
@@ -483,6 +530,7 @@ static int inner_solve(Problem &P, int kind, const double *b, double *x) {
     }
     P.inner_its += its;
   }
+  if (P.winv_status != ALFD_OK) return P.winv_status;
   if (st == FAILURE) {
     if (std::isnan(res)) return ALFD_E_BREAKDOWN;
     if (P.cfg.on_inner_failure == ALFD_INNER_THROW) return ALFD_E_NO_CONVERGENCE_INNER;
@@ -552,6 +600,13 @@ static void setup(Problem &P) {
     rational_setup(P);
     P.lambda_max = P.lam_max[OP_K];
     return;
+  }
+  if (P.cfg.w_inverse != ALFD_W_DIAGONAL) {
+    const Csr &M = P.mat[ALFD_M];
+    P.dinv_m.assign(M.nrows, 0.0);
+    for (int64_t i = 0; i < M.nrows; ++i)
+      for (int64_t k = M.rp[i]; k < M.rp[i + 1]; ++k)
+        if (M.col[k] == i) P.dinv_m[i] = 1.0 / M.val[k];
   }
   P.dinv_aug.assign(P.n[0], 0.0);
   diag_plus(P.mat[ALFD_A], P.mat[ALFD_CT], w, P.cfg.aug_assembled ? 0.0 : P.cfg.gamma, P.n[0], P.dinv_aug.data());
@@ -826,7 +881,10 @@ static int precond_apply(Problem &P, const double *u, double *v) {
     // augmented_lagrangian_preconditioner.h:28-34
     const double *u0 = u + P.off[0], *u1 = u + P.off[1];
     double *v0 = v + P.off[0], *v1 = v + P.off[1];
-    pmul_scale(P.n[1], -c.gamma, w, u1, v1);            // v1 = -gamma invW u1
+    {                                                   // v1 = -gamma invW u1
+      const int rc = winv_scale(P, -c.gamma, u1, v1);
+      if (rc != ALFD_OK) return rc;
+    }
     std::vector<double> tmp(u0, u0 + P.n[0]);
     spmv(P.mat[ALFD_CT], v1, tmp.data(), 1, -1.0);      // tmp = u0 - Ct v1
     return inner_solve(P, OP_AUG, tmp.data(), v0);      // v0 = Aug_inv tmp
@@ -837,9 +895,10 @@ static int precond_apply(Problem &P, const double *u, double *v) {
     const double sgn = tri ? -1.0 : 1.0;
     const double *u0 = u + P.off[0], *u1 = u + P.off[1], *u2 = u + P.off[2];
     double *v0 = v + P.off[0], *v1 = v + P.off[1], *v2 = v + P.off[2];
-    pmul_scale(P.n[2], sgn * c.gamma, w, u2, v2);       // v2 = -+gamma invW u2
+    int rc = winv_scale(P, sgn * c.gamma, u2, v2);      // v2 = -+gamma invW u2
+    if (rc != ALFD_OK) return rc;
     std::vector<double> q(P.n[1]);
-    int rc = inner_solve(P, OP_MP, u1, q.data());       // Mp_inv u1
+    rc = inner_solve(P, OP_MP, u1, q.data());           // Mp_inv u1
     if (rc != ALFD_OK) return rc;
     const double s1 = sgn * c.gamma_grad_div;
     for (int64_t i = 0; i < P.n[1]; ++i) v1[i] = s1 * q[i];
@@ -903,7 +962,12 @@ static int system_apply(Problem &P, const double *x, double *y) {
     spmv(C, x0, yl, 0, 0.0);                            // y_lambda = C x0
     if (!c.aug_assembled) {
       std::vector<double> t(C.nrows);
-      pmul(C.nrows, w, yl, t.data());
+      if (c.w_inverse != ALFD_W_DIAGONAL) {
+        const int rc = winv_scale(P, 1.0, yl, t.data());
+        if (rc != ALFD_OK) return rc;
+      } else {
+        pmul(C.nrows, w, yl, t.data());
+      }
       spmv(P.mat[ALFD_CT], t.data(), y0, 1, c.gamma);   // + gamma Ct invW C x0
     }
     if (P.nblocks == 3) {
@@ -1234,6 +1298,10 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
         P.pt.offs[b][r] = op->part_offsets[b] ? op->part_offsets[b][r] : P.n[b] * r / P.pt.nranks;
     }
   }
+  if (cfg->w_inverse != ALFD_W_DIAGONAL) {
+    if (cfg->variant == ALFD_RATIONAL || ell) return ALFD_E_UNSUPPORTED;
+    if (!P.mat[ALFD_M].present() || P.mat[ALFD_M].nrows != P.n[P.nblocks - 1]) return ALFD_E_NOT_SETUP;
+  }
   orc::setup(P);
   return ALFD_OK;
 }
@@ -1254,6 +1322,7 @@ static void fill_result(const orc::Problem &P, alfd_result *res, int status) {
   res->precond_applications = P.precond_applications;
   res->lambda_max = P.lambda_max;
   res->rational_iterations = P.rational_its;
+  res->mass_iterations = P.mass_its;
 }
 
 int orc_spmv(const orc_csr *m, int lanes, int vec, const double *x, double *y, int mode, double alpha) {
@@ -1292,7 +1361,7 @@ int orc_h_precond_apply(void *h, const alfd_control *inner_override, const doubl
                         double *const *dst, alfd_result *res) {
   orc::Problem &P = *static_cast<orc::Problem *>(h);
   if (inner_override) P.cfg.inner = *inner_override;
-  P.inner_its = P.mp_its = P.rational_its = 0;
+  P.inner_its = P.mp_its = P.rational_its = P.mass_its = 0;
   P.inner_failures = P.precond_applications = 0;
   std::vector<double> u, v(P.ntot(), 0.0);
   pack(P, src, u);
@@ -1336,7 +1405,12 @@ int orc_augment_rhs(const orc_problem *op, const alfd_config *cfg, double *const
   if (rc != ALFD_OK) return rc;
   const int last = P.nblocks - 1;
   std::vector<double> t(P.n[last]);
-  orc::pmul(P.n[last], P.diag[ALFD_INVW], rhs[last], t.data());
+  if (cfg->w_inverse != ALFD_W_DIAGONAL) {
+    rc = orc::winv_scale(P, 1.0, rhs[last], t.data());
+    if (rc != ALFD_OK) return rc;
+  } else {
+    orc::pmul(P.n[last], P.diag[ALFD_INVW], rhs[last], t.data());
+  }
   orc::spmv(P.mat[ALFD_CT], t.data(), rhs[0], 1, cfg->gamma);
   return ALFD_OK;
 }

@@ -215,6 +215,8 @@ def system_from_problem(pb, nranks_emulated=1, part_offsets=None, aggregates=Non
         return OracleSystem(mats, {_abi.INVW: pb.inv_w_diag_of_mass_squared()}, pb.block_sizes,
                             nranks_emulated, part_offsets, aggregates)
     diags = {_abi.INVW: pb.inv_w_diag_squared()}
+    if "M" in pb.mats:      # exact W^-1 modes run CG on the immersed mass matrix
+        mats["M"] = pb.mats["M"]
     if "B" in pb.mats:
         mats.update({k: pb.mats[k] for k in ("B", "Bt", "Mp")})
         diags[_abi.MP_LUMPED_INV] = pb.mp_lumped_inv()

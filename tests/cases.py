@@ -81,6 +81,28 @@ def case(name):
         cfg = _abi.default_config(_abi.AL2)
         cfg.gamma, cfg.aug_assembled = gamma_h, 1
         cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
+    elif name in ("laplace2d_exact_w", "stokes2d_exact_w", "laplace2d_operator_form_exact_w"):
+        # `Use diagonal inverse = false`: W^-1 = (M^-1)^2, or M^-1 in operator
+        # form (immersed_laplace.cc:859-877, stokes...:979-985; UMFPACK there, CG on M here).  The inner
+        # preconditioner keeps the diagonal weight, as the reference's AMG does.
+        if name.startswith("stokes"):
+            pb = problems.stokes2d_circle(16, 3)            # parameters_stokes.prm:22
+            cfg = _abi.default_config(_abi.AL_STOKES)
+            cfg.w_inverse = _abi.W_MASS_INV_SQUARED
+        elif name == "laplace2d_exact_w":
+            pb = problems.laplace2d_circle(32, 3)           # Circle_parameters_f0_g1.prm:11-14
+            cfg = _abi.default_config(_abi.AL2)
+            cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
+            cfg.w_inverse = _abi.W_MASS_INV_SQUARED
+        else:
+            pb = problems.laplace2d_circle(32, 3, surface_mass=True)
+            a_op, gamma_h, inv_w = problems.operator_form(pb)
+            pb.mats = dict(pb.mats, A=a_op)
+            pb.inv_w_override = inv_w
+            cfg = _abi.default_config(_abi.AL2)
+            cfg.gamma, cfg.aug_assembled = gamma_h, 1
+            cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
+            cfg.w_inverse = _abi.W_MASS_INV
     elif name in ("stokes3d_multilevel", "laplace3d_multilevel", "elliptic_modified_multilevel"):
         # aggregation-multigrid inner preconditioner (ML in the reference)
         if name.startswith("stokes"):
@@ -114,7 +136,8 @@ def aggregates_of(pb, cfg):
 ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes2d_circle", "stokes3d_sphere",
              "stokes3d_restart", "elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3",
              "rational_minres", "stokes_minres_diag", "stokes3d_multilevel", "laplace3d_multilevel",
-             "elliptic_modified_multilevel", "laplace2d_operator_form"]
+             "elliptic_modified_multilevel", "laplace2d_operator_form", "laplace2d_exact_w", "stokes2d_exact_w",
+             "laplace2d_operator_form_exact_w"]
 
 
 def oracle_system(pb, cfg):

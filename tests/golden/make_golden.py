@@ -32,6 +32,7 @@ def main():
             "inner_iterations": res.inner_iterations,
             "mp_iterations": res.mp_iterations,
             "rational_iterations": res.rational_iterations,
+            "mass_iterations": res.mass_iterations,
             "lambda_max": float(res.lambda_max).hex(),
             "history": [float(h).hex() for h in hist],
             "x_block_norms": [float((b * b).sum() ** 0.5).hex() for b in x],

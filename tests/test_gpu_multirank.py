@@ -129,3 +129,28 @@ def test_partitioned_multilevel_solve_matches_oracle_emulation(built, world):
     cfg2.inner.max_steps = 1000
     _, out2 = _run_ranks(world, n, ref, cfg2)
     assert out[0]["res"]["inner_iterations"] < out2[0]["res"]["inner_iterations"]
+
+
+def test_partitioned_exact_w_inverse_matches_oracle_emulation(built):
+    """`Diagonal mass immersed = false` on the row-partitioned path: the nested CG on the
+    (row-partitioned, halo-exchanging) immersed mass matrix inside the operator of the inner CG,
+    reductions in rank order -- same counts as the oracle's emulation of the partition."""
+    world, n, ref = 2, 8, 0
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    cfg.inner.max_steps = 1000
+    cfg.w_inverse = _abi.W_MASS_INV_SQUARED
+    plan, out = _run_ranks(world, n, ref, cfg)
+    full = problems.stokes3d_sphere(n, ref)
+    osys = oracle.system_from_problem(full, nranks_emulated=world, part_offsets=plan.offsets)
+    rc, orhs = osys.augment_rhs(cfg, cases.rhs_of(full))
+    assert rc == 0
+    rc, ox, ores, ohist = osys.solve(cfg, orhs)
+    assert rc == 0 and ores.mass_iterations > 0
+    for r in range(world):
+        res = out[r]["res"]
+        assert res["status"] == 0
+        assert (res["outer_iterations"], res["inner_iterations"], res["mp_iterations"], res["mass_iterations"]) == \
+            (ores.outer_iterations, ores.inner_iterations, ores.mp_iterations, ores.mass_iterations)
+        assert np.max(np.abs(out[r]["hist"] - ohist) / np.abs(ohist)) <= 1e-10
+    for b in range(3):
+        assert np.array_equal(np.concatenate([out[r]["rhs"][b] for r in range(world)]), orhs[b])

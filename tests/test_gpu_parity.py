@@ -166,6 +166,7 @@ def test_precond_vmult_parity(ctxs, name):
     assert res.inner_iterations == ores.inner_iterations
     assert res.mp_iterations == ores.mp_iterations
     assert res.rational_iterations == ores.rational_iterations
+    assert res.mass_iterations == ores.mass_iterations
     assert res.lambda_max == ores.lambda_max
     for g, r in zip(got, ref):
         assert np.allclose(g, r, rtol=HIST_RTOL, atol=HIST_RTOL * np.abs(r).max())
@@ -197,6 +198,7 @@ def test_solve_matches_oracle_and_golden(ctxs, name):
     assert res.inner_iterations == ores.inner_iterations
     assert res.mp_iterations == ores.mp_iterations
     assert res.rational_iterations == ores.rational_iterations
+    assert res.mass_iterations == ores.mass_iterations
     assert len(hist) == len(ohist)
     assert np.max(np.abs(hist - ohist) / np.abs(ohist)) <= HIST_RTOL
     for g, r in zip(x, ox):

@@ -216,6 +216,7 @@ def test_golden_fixtures(name):
     rc, x, res, hist = osys.solve(cfg, rhs)
     assert rc == 0
     assert res.rational_iterations == gold["rational_iterations"]
+    assert res.mass_iterations == gold["mass_iterations"]
     assert res.outer_iterations == gold["outer_iterations"]
     assert res.inner_iterations == gold["inner_iterations"]
     assert res.mp_iterations == gold["mp_iterations"]
@@ -375,3 +376,40 @@ def test_multilevel_hierarchy_and_preconditioner_quality():
     assert res.inner_iterations < 0.7 * res2.inner_iterations          # 121 vs 206
     # velocities agree (the pressure is only defined up to a constant with all-Dirichlet velocity)
     assert np.linalg.norm(x[0] - x2[0]) <= 1e-5 * np.linalg.norm(x2[0])
+
+
+def test_exact_w_inverse_matches_sparse_direct():
+    """`Use diagonal inverse = false`: W^-1 = (M^-1)^2 through CG on the immersed mass matrix
+    (UMFPACK in the reference, immersed_laplace.cc:874-877) against SciPy's sparse LU; the
+    preconditioner's multiplier block is v1 = -gamma W^-1 u1 (augmented_lagrangian_preconditioner.h:29)."""
+    import scipy.sparse.linalg as spla
+    pb, cfg = cases.case("laplace2d_exact_w")
+    osys = cases.oracle_system(pb, cfg)
+    src = cases.rng_blocks(pb, 21)
+    rc, v, _ = osys.precond_apply(cfg, src)
+    assert rc == 0
+    lu = spla.splu(pb.mats["M"].to_scipy().tocsc())
+    ref = -cfg.gamma * lu.solve(lu.solve(src[1]))
+    assert np.abs(v[1] - ref).max() <= 1e-11 * np.abs(ref).max()
+    # operator form: W^-1 = M^-1
+    pb, cfg = cases.case("laplace2d_operator_form_exact_w")
+    osys = cases.oracle_system(pb, cfg)
+    src = cases.rng_blocks(pb, 22)
+    rc, v, _ = osys.precond_apply(cfg, src)
+    assert rc == 0
+    lu = spla.splu(pb.mats["M"].to_scipy().tocsc())
+    ref = -cfg.gamma * lu.solve(src[1])
+    assert np.abs(v[1] - ref).max() <= 1e-11 * np.abs(ref).max()
+    # fewer outer iterations than with the diagonal weight, as in the reference's tables
+    rhs = cases.prepared_rhs(osys, pb, cfg)
+    rc, _, res, _ = osys.solve(cfg, rhs)
+    cfg_d = _abi.Config.from_buffer_copy(cfg)
+    cfg_d.w_inverse = _abi.W_DIAGONAL
+    rc2, _, res_d, _ = osys.solve(cfg_d, cases.prepared_rhs(osys, pb, cfg_d))
+    assert rc == 0 and rc2 == 0 and res.mass_iterations > 0 and res_d.mass_iterations == 0
+    assert res.outer_iterations < res_d.outer_iterations
+    # not available for the elliptic-interface / rational variants
+    pb, cfg = cases.case("elliptic_modified")
+    cfg.w_inverse = _abi.W_MASS_INV_SQUARED
+    rc, _, _ = cases.oracle_system(pb, cfg).precond_apply(cfg, cases.rng_blocks(pb, 1))
+    assert rc == _abi.E_UNSUPPORTED

@@ -71,7 +71,12 @@ def test_immersed_laplace_and_elliptic_sections():
     cfg, info = prm.config_from_prm(lap)
     assert cfg.variant == _abi.AL2 and cfg.gamma == 10.0 and cfg.outer.tol == 1e-10 and cfg.outer.reduce == 1e-12
     assert cfg.aug_assembled == 1 and info["gamma_needs_h_scaling"]      # operator form: supported
-    assert len(info["unsupported"]) == 1         # the UMFPACK W is flagged, not guessed
+    assert not info["unsupported"] and cfg.w_inverse == _abi.W_MASS_INV          # operator form + exact W: M^-1
+    lap2 = prm.parse("subsection Distributed Lagrange<1,2>\n set Solver = augmented\n"
+                     " subsection AL preconditioner\n set Use diagonal inverse = false\n end\nend\n")
+    cfg2, info2 = prm.config_from_prm(lap2)
+    assert cfg2.w_inverse == _abi.W_MASS_INV_SQUARED and cfg2.aug_assembled == 0  # immersed_laplace.cc:874-877
+    assert (cfg2.mass.kind, cfg2.mass.max_steps, cfg2.mass.reduce) == (_abi.CTRL_REDUCTION, 1000, 1e-14)
     ell = prm.parse("subsection Elliptic Interface Problem\n set Beta_2 = 10\n subsection AL preconditioner\n"
                     " set Use modified AL preconditioner = true\n set gamma fluid = 10\n set gamma solid = 1e-2\n end\n"
                     " subsection Inner solver control\n set Max steps = 100000\n set Reduction = 1.e-20\n set Tolerance = 1.e-2\n end\n"
