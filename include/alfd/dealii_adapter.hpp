@@ -10,6 +10,8 @@
 //     sys.set_matrix(ALFD_MP, preconditioner_matrix.block(1, 1));
 //     sys.set_diag(ALFD_INVW, inverse_squares);             // DiagonalMatrix<Vector<double>>
 //     sys.set_diag(ALFD_MP_LUMPED_INV, pressure_diagonal_inv);
+//     // `Diagonal mass immersed = false` (stokes...:979-985): cfg.w_inverse = ALFD_W_MASS_INV_SQUARED and
+//     // sys.set_matrix(ALFD_M, mass_matrix) -- the UMFPACK solves become CG on M inside the library
 //     sys.configure(cfg); sys.setup();
 //     BlockPreconditionerAugmentedLagrangianStokes P(sys);  // vmult(v, u) const
 //     SolverFGMRES<BlockVector<double>> solver(sys);        // solve(AA, x, b, P)
