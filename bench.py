@@ -42,8 +42,8 @@ def main():
     ap.add_argument("--inner-max", type=int, default=2000)
     ap.add_argument("--inner-prec", choices=["chebyshev", "multilevel"],
                     default=os.environ.get("ALFD_BENCH_PREC", "multilevel"))
-    ap.add_argument("--ml-smooth-degree", type=int, default=2)
-    ap.add_argument("--ml-smooth-ratio", type=float, default=8.0)
+    ap.add_argument("--ml-smooth-degree", type=int, default=3)
+    ap.add_argument("--ml-smooth-ratio", type=float, default=64.0)
     ap.add_argument("--ml-coarse-degree", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only-spmv", type=int, default=0,
