@@ -709,7 +709,12 @@ static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y, bool exac
       return spmv(ctx, ALFD_A, x, y, 0);
     case OP_A22:
       RC(spmv(ctx, ALFD_A2, x, y, 0));
-      RC(spmv(ctx, ALFD_M, x, ctx->t_lam, 2, 0.0, w));
+      if (exact_w && ctx->cfg.w_inverse != ALFD_W_DIAGONAL) {
+        RC(spmv(ctx, ALFD_M, x, ctx->t_lam, 0));
+        RC(winv_scale(ctx, 1.0, ctx->t_lam, ctx->t_lam));
+      } else {
+        RC(spmv(ctx, ALFD_M, x, ctx->t_lam, 2, 0.0, w));
+      }
       return spmv(ctx, ALFD_M, ctx->t_lam, y, 1, ctx->cfg.gamma2);
     default: {
       const double *x1 = x + ctx->off[1];
@@ -717,7 +722,8 @@ static int op_apply(alfd_ctx *ctx, int op, const double *x, double *y, bool exac
       const int64_t nlp = pad_chunk(ctx->n[2]);
       RC(spmv(ctx, ALFD_C, x, ctx->t_lam, 0));
       RC(spmv(ctx, ALFD_M, x1, ctx->t_lam, 1, -1.0));
-      VEC_LAUNCH(pmul_scale_kernel, nlp, 24, 1.0, w, ctx->t_lam, ctx->t_lam);
+      if (exact_w) RC(winv_scale(ctx, 1.0, ctx->t_lam, ctx->t_lam));  // diagonal weight unless w_inverse says otherwise
+      else VEC_LAUNCH(pmul_scale_kernel, nlp, 24, 1.0, w, ctx->t_lam, ctx->t_lam);
       RC(spmv(ctx, ALFD_A, x, y, 0));
       RC(spmv(ctx, ALFD_CT, ctx->t_lam, y, 1, ctx->cfg.gamma));
       RC(spmv(ctx, ALFD_A2, x1, y1, 0));
@@ -1016,11 +1022,16 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
   if (c.variant == ALFD_AL_ELL_MODIFIED) {
     // BlockTriangularALPreconditionerModified::vmult, ...preconditioner.h:225-228
     double *d0 = v + off[0], *d1 = v + off[1], *d2 = v + off[2];
-    VEC_LAUNCH(pmul_scale_kernel, n2p, 24, -c.gamma, w, u + off[2], d2);        // d2 = -gamma invW lambda
+    RC(winv_scale(ctx, -c.gamma, u + off[2], d2));                              // d2 = -gamma invW lambda
     HIPC(hipMemcpyAsync(ctx->q_tmp, u + off[1], n1p * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     RC(spmv(ctx, ALFD_M, d2, ctx->q_tmp, 1, 1.0));                              // u2 + M d2
     RC(inner_solve(ctx, OP_A22, ctx->q_tmp, d1));                               // d1 = A22_inv (...)
-    RC(spmv(ctx, ALFD_M, d1, ctx->t_lam, 2, 0.0, w));                           // t = invW M d1
+    if (c.w_inverse != ALFD_W_DIAGONAL) {                                        // t = invW M d1
+      RC(spmv(ctx, ALFD_M, d1, ctx->t_lam, 0));
+      RC(winv_scale(ctx, 1.0, ctx->t_lam, ctx->t_lam));
+    } else {
+      RC(spmv(ctx, ALFD_M, d1, ctx->t_lam, 2, 0.0, w));
+    }
     HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
                         ctx->stream));
     RC(spmv(ctx, ALFD_CT, ctx->t_lam, ctx->rhs_tmp, 1, c.gamma));               // u + gamma Ct t
@@ -1029,7 +1040,7 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
   }
   if (c.variant == ALFD_AL_ELL_IDEAL) {
     // BlockTriangularALPreconditioner::vmult, ...preconditioner.h:130-156
-    VEC_LAUNCH(pmul_scale_kernel, n2p, 24, -c.gamma, w, u + off[2], v + off[2]);
+    RC(winv_scale(ctx, -c.gamma, u + off[2], v + off[2]));
     HIPC(hipMemcpyAsync(ctx->rhs_tmp, u, off[2] * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     RC(spmv(ctx, ALFD_CT, v + off[2], ctx->rhs_tmp, 1, -1.0));                  // u0 - Ct v2
     RC(spmv(ctx, ALFD_M, v + off[2], ctx->rhs_tmp + off[1], 1, 1.0));           // u1 + M v2
@@ -1083,7 +1094,7 @@ static int system_apply(alfd_ctx *ctx, const double *x, double *y) {
     double *y0 = y + off[0], *y1 = y + off[1], *y2 = y + off[2];
     RC(spmv(ctx, ALFD_C, x0, y2, 0));
     RC(spmv(ctx, ALFD_M, x1, y2, 1, -1.0));                                     // y2 = C x0 - M x1
-    VEC_LAUNCH(pmul_scale_kernel, pad_chunk(ctx->n[2]), 24, 1.0, w, y2, ctx->t_lam);
+    RC(winv_scale(ctx, 1.0, y2, ctx->t_lam));
     RC(spmv(ctx, ALFD_A, x0, y0, 0));
     RC(spmv(ctx, ALFD_CT, ctx->t_lam, y0, 1, c.gamma));
     RC(spmv(ctx, ALFD_CT, x2, y0, 1, 1.0));
@@ -2330,8 +2341,7 @@ static int setup(alfd_ctx *ctx) {
     // exact W^-1 = (M^-1)^2 or M^-1: nested Jacobi CG on the immersed mass matrix
     if (c.w_inverse != ALFD_W_MASS_INV_SQUARED && c.w_inverse != ALFD_W_MASS_INV)
       return ctx->err = "unknown alfd_config::w_inverse", ALFD_E_INVALID;
-    if (rat || ell)
-      return ctx->err = "exact W^-1 is implemented for the AL2 and Stokes variants", ALFD_E_UNSUPPORTED;
+    if (rat) return ctx->err = "the rational variant has no W^-1", ALFD_E_UNSUPPORTED;
     const HostCsr &M = ctx->h_M;
     if (!ctx->mat[ALFD_M].present || M.rp.empty() || M.nrows != ctx->n[last])
       return ctx->err = "slot M (immersed mass matrix) must be set for the exact W^-1", ALFD_E_NOT_SETUP;

@@ -158,7 +158,11 @@ def config_from_prm(tree: dict) -> tuple[_abi.Config, dict]:
             raise ValueError("Parameter gamma is probably too small for classical AL preconditioner")
         if not modified and abs(cfg.gamma - cfg.gamma2) >= 1e-12:
             raise ValueError("In the ideal case, gamma must be identical")
+        h_scaled = _b(al.get("Use h-scaled mass"), False) or _b(al.get("Use operator version"), False)
+        info["h_scaled_or_operator_form"] = h_scaled
         if not info["diagonal_W"]:
-            info["unsupported"].append("Use diagonal inverse = false (UMFPACK M^-1 M^-1)")
+            # elliptic_interface.cc:703-737: invW = M^-1 with the h-scaled mass / operator form, M^-1 M^-1
+            # otherwise (UMFPACK there, CG on slot M here)
+            cfg.w_inverse = _abi.W_MASS_INV if h_scaled else _abi.W_MASS_INV_SQUARED
         return cfg, info
     raise ValueError("no known driver section in this .prm")

@@ -137,7 +137,7 @@ enum alfd_inner_failure_policy { ALFD_INNER_THROW = 0, ALFD_INNER_ACCEPT = 1 };
  * (ALFD_INVW: 1/M_ii^2, or 1/M_ii in operator form) -- `Use diagonal inverse = true`.
  * MASS_INV_SQUARED / MASS_INV: the exact (M^-1)^2 / M^-1 of the reference's
  * `Use diagonal inverse = false` branch (immersed_laplace.cc:866-877, stokes...:979-985,
- * UMFPACK there): every application runs Jacobi-preconditioned CG on the immersed mass
+ * elliptic_interface.cc:713-737; UMFPACK there): every application runs Jacobi-preconditioned CG on the immersed mass
  * matrix (slot ALFD_M) to alfd_config::mass.  The inner preconditioner (Jacobi /
  * Chebyshev / multilevel) keeps using the diagonal weight, as the reference builds its
  * AMG from the diagonal form in either case (utilities.h:218-331). */

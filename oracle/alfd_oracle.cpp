@@ -336,7 +336,8 @@ struct InnerOp {
       spmv(P.mat[ALFD_A2], x, y, 0, 0.0);
       t.resize(M.nrows);
       spmv(M, x, t.data(), 0, 0.0);
-      pmul(M.nrows, w, t.data(), t.data());
+      if (exact_w && P.cfg.w_inverse != ALFD_W_DIAGONAL) winv_scale(P, 1.0, t.data(), t.data());
+      else pmul(M.nrows, w, t.data(), t.data());
       spmv(M, t.data(), y, 1, P.cfg.gamma2);
     } else {
       const Csr &C = P.mat[ALFD_C], &M = P.mat[ALFD_M];
@@ -345,7 +346,8 @@ struct InnerOp {
       t.resize(C.nrows);
       spmv(C, x0, t.data(), 0, 0.0);
       spmv(M, x1, t.data(), 1, -1.0);                    // s = C x0 - M x1
-      pmul(C.nrows, w, t.data(), t.data());
+      if (exact_w && P.cfg.w_inverse != ALFD_W_DIAGONAL) winv_scale(P, 1.0, t.data(), t.data());
+      else pmul(C.nrows, w, t.data(), t.data());
       spmv(P.mat[ALFD_A], x0, y0, 0, 0.0);
       spmv(P.mat[ALFD_CT], t.data(), y0, 1, P.cfg.gamma);
       spmv(P.mat[ALFD_A2], x1, y1, 0, 0.0);
@@ -916,14 +918,20 @@ static int precond_apply(Problem &P, const double *u, double *v) {
     //   d0 = A11_inv (u + gamma Ct invW M d1 - Ct d2)
     const double *u0 = u + P.off[0], *u1 = u + P.off[1], *u2 = u + P.off[2];
     double *d0 = v + P.off[0], *d1 = v + P.off[1], *d2 = v + P.off[2];
-    pmul_scale(P.n[2], -c.gamma, w, u2, d2);
+    int rc = winv_scale(P, -c.gamma, u2, d2);
+    if (rc != ALFD_OK) return rc;
     std::vector<double> r1(u1, u1 + P.n[1]);
     spmv(P.mat[ALFD_M], d2, r1.data(), 1, 1.0);
-    int rc = inner_solve(P, OP_A22, r1.data(), d1);
+    rc = inner_solve(P, OP_A22, r1.data(), d1);
     if (rc != ALFD_OK) return rc;
     std::vector<double> t(P.n[2]), r0(u0, u0 + P.n[0]);
     spmv(P.mat[ALFD_M], d1, t.data(), 0, 0.0);
-    pmul(P.n[2], w, t.data(), t.data());
+    if (c.w_inverse != ALFD_W_DIAGONAL) {
+      rc = winv_scale(P, 1.0, t.data(), t.data());
+      if (rc != ALFD_OK) return rc;
+    } else {
+      pmul(P.n[2], w, t.data(), t.data());
+    }
     spmv(P.mat[ALFD_CT], t.data(), r0.data(), 1, c.gamma);
     spmv(P.mat[ALFD_CT], d2, r0.data(), 1, -1.0);
     return inner_solve(P, OP_AUG, r0.data(), d0);
@@ -933,7 +941,10 @@ static int precond_apply(Problem &P, const double *u, double *v) {
     //   v2 = -gamma invW u2 ; [v0;v1] = Aug2x2_inv [u0 - Ct v2 ; u1 + M v2]
     const double *u2 = u + P.off[2];
     double *v2 = v + P.off[2];
-    pmul_scale(P.n[2], -c.gamma, w, u2, v2);
+    {
+      const int rc = winv_scale(P, -c.gamma, u2, v2);
+      if (rc != ALFD_OK) return rc;
+    }
     std::vector<double> uu(u, u + P.off[2]);
     spmv(P.mat[ALFD_CT], v2, uu.data(), 1, -1.0);
     spmv(P.mat[ALFD_M], v2, uu.data() + P.off[1], 1, 1.0);
@@ -995,7 +1006,12 @@ static int system_apply(Problem &P, const double *x, double *y) {
     spmv(P.mat[ALFD_C], x0, y2, 0, 0.0);
     spmv(M, x1, y2, 1, -1.0);
     std::vector<double> t(P.n[2]);
-    pmul(P.n[2], w, y2, t.data());
+    if (c.w_inverse != ALFD_W_DIAGONAL) {
+      const int rc = winv_scale(P, 1.0, y2, t.data());
+      if (rc != ALFD_OK) return rc;
+    } else {
+      pmul(P.n[2], w, y2, t.data());
+    }
     spmv(P.mat[ALFD_A], x0, y0, 0, 0.0);
     spmv(P.mat[ALFD_CT], t.data(), y0, 1, c.gamma);
     spmv(P.mat[ALFD_CT], x2, y0, 1, 1.0);
@@ -1299,7 +1315,7 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
     }
   }
   if (cfg->w_inverse != ALFD_W_DIAGONAL) {
-    if (cfg->variant == ALFD_RATIONAL || ell) return ALFD_E_UNSUPPORTED;
+    if (cfg->variant == ALFD_RATIONAL) return ALFD_E_UNSUPPORTED;
     if (!P.mat[ALFD_M].present() || P.mat[ALFD_M].nrows != P.n[P.nblocks - 1]) return ALFD_E_NOT_SETUP;
   }
   orc::setup(P);

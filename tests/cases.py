@@ -103,6 +103,16 @@ def case(name):
             cfg.gamma, cfg.aug_assembled = gamma_h, 1
             cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
             cfg.w_inverse = _abi.W_MASS_INV
+    elif name in ("elliptic_modified_exact_w", "elliptic_ideal_exact_w"):
+        # elliptic_interface with `Use diagonal inverse = false`: invW = M^-1 M^-1 (elliptic...:733-737;
+        # parameters_ideal.prm:38)
+        pb = problems.elliptic_interface2d(32, 8)
+        ideal = name.startswith("elliptic_ideal")
+        cfg = _abi.default_config(_abi.AL_ELL_IDEAL if ideal else _abi.AL_ELL_MODIFIED)
+        cfg.gamma, cfg.gamma2 = 10.0, (10.0 if ideal else 1e-2)
+        cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 100000, 1e-2, 1e-20)
+        cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-10)
+        cfg.w_inverse = _abi.W_MASS_INV_SQUARED
     elif name in ("stokes3d_multilevel", "laplace3d_multilevel", "elliptic_modified_multilevel"):
         # aggregation-multigrid inner preconditioner (ML in the reference)
         if name.startswith("stokes"):
@@ -137,7 +147,7 @@ ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes
              "stokes3d_restart", "elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3",
              "rational_minres", "stokes_minres_diag", "stokes3d_multilevel", "laplace3d_multilevel",
              "elliptic_modified_multilevel", "laplace2d_operator_form", "laplace2d_exact_w", "stokes2d_exact_w",
-             "laplace2d_operator_form_exact_w"]
+             "laplace2d_operator_form_exact_w", "elliptic_modified_exact_w", "elliptic_ideal_exact_w"]
 
 
 def oracle_system(pb, cfg):

@@ -408,8 +408,17 @@ def test_exact_w_inverse_matches_sparse_direct():
     rc2, _, res_d, _ = osys.solve(cfg_d, cases.prepared_rhs(osys, pb, cfg_d))
     assert rc == 0 and rc2 == 0 and res.mass_iterations > 0 and res_d.mass_iterations == 0
     assert res.outer_iterations < res_d.outer_iterations
-    # not available for the elliptic-interface / rational variants
-    pb, cfg = cases.case("elliptic_modified")
+    # elliptic interface, ideal preconditioner: v2 = -gamma (M^-1)^2 u2 (elliptic_interface.cc:733-737)
+    pb, cfg = cases.case("elliptic_ideal_exact_w")
+    osys = cases.oracle_system(pb, cfg)
+    src = cases.rng_blocks(pb, 23)
+    rc, v, _ = osys.precond_apply(cfg, src)
+    assert rc == 0
+    lu = spla.splu(pb.mats["M"].to_scipy().tocsc())
+    ref = -cfg.gamma * lu.solve(lu.solve(src[2]))
+    assert np.abs(v[2] - ref).max() <= 1e-11 * np.abs(ref).max()
+    # the rational variant has no W^-1
+    pb, cfg = cases.case("rational_minres")
     cfg.w_inverse = _abi.W_MASS_INV_SQUARED
     rc, _, _ = cases.oracle_system(pb, cfg).precond_apply(cfg, cases.rng_blocks(pb, 1))
     assert rc == _abi.E_UNSUPPORTED
