@@ -24,24 +24,6 @@ constexpr int64_t kChunk = 4096;     // dot chunk == vector padding granule
 constexpr int kMaxBasis = 64;        // max FGMRES basis vectors handled by the batched kernels
 
 // --------------------------------------------------------------------------
-// wave / group reductions (xor butterfly; all lanes end with the tree value)
-template <int L>
-__device__ __forceinline__ double group_reduce(double v) {
-#pragma unroll
-  for (int s = L / 2; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
-  return v;
-}
-
-// block of 256 threads -> (w0+w1)+(w2+w3), valid in thread 0
-__device__ __forceinline__ double block_reduce_256(double v, double *lds4) {
-  v = group_reduce<64>(v);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) lds4[wave] = v;
-  __syncthreads();
-  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
-}
-
-// --------------------------------------------------------------------------
 // Several 64-lane trees at once, on the vector ALU only (no LDS-pipe shuffles).
 // The canonical tree adds partner lanes l^32, l^16, l^8, l^4, l^2, l^1 in that
 // order.  v_permlane32_swap / v_permlane16_swap exchange half-waves / 16-lane rows
@@ -82,6 +64,30 @@ __device__ __forceinline__ void swap16(double &a, double &b) {
   a = __hiloint2double((int)h[0], (int)l[0]);
   b = __hiloint2double((int)h[1], (int)l[1]);
 }
+// --------------------------------------------------------------------------
+// wave / group reductions: the canonical tree adds partner lanes l^(L/2), ..., l^2, l^1 in that
+// order (all lanes end with the tree value).  Evaluated on the vector ALU: half-wave and
+// 16-lane-row exchanges by v_permlane32_swap / v_permlane16_swap on two copies of the value,
+// the last four steps by DPP moves -- no ds_bpermute, same pairs in the same order.
+template <int L>
+__device__ __forceinline__ double group_reduce(double v) {
+  if (L >= 64) {
+    double a = v, b = v;
+    swap32(a, b);  // a = [lo | lo], b = [hi | hi]
+    v = a + b;
+  }
+  if (L >= 32) {
+    double p = v, q = v;
+    swap16(p, q);  // p = rows [0,0,2,2], q = rows [1,1,3,3]
+    v = p + q;
+  }
+  if (L >= 16) v = v + dpp_xor_mov(v, 8);
+  if (L >= 8) v = v + dpp_xor_mov(v, 4);
+  if (L >= 4) v = v + dpp_xor_mov(v, 2);
+  if (L >= 2) v = v + dpp_xor_mov(v, 1);
+  return v;
+}
+
 __device__ __forceinline__ double row16_tree(double v) {
   v = v + dpp_xor_mov(v, 8);
   v = v + dpp_xor_mov(v, 4);
@@ -104,6 +110,15 @@ __device__ __forceinline__ double reduce_rows2(double a0, double a1) {
   double p = a0 + a1, q = p;
   swap16(p, q);  // p = rows [0,0,2,2], q = rows [1,1,3,3] of the old p
   return row16_tree(p + q);
+}
+
+// block of 256 threads -> (w0+w1)+(w2+w3), valid in thread 0
+__device__ __forceinline__ double block_reduce_256(double v, double *lds4) {
+  v = group_reduce<64>(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) lds4[wave] = v;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
 // --------------------------------------------------------------------------
