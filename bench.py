@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--ml-smooth-ratio", type=float, default=64.0)
     ap.add_argument("--ml-coarse-degree", type=int, default=10)
     ap.add_argument("--agg-a", type=int, default=2, help="nodes per aggregate edge (geometric aggregation)")
+    ap.add_argument("--min-coarse", type=int, default=600, help="stop coarsening below this many unknowns")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only-spmv", type=int, default=0,
                     help="skip the solve; run this many back-to-back A SpMV launches (for rocprofv3)")
@@ -107,7 +108,7 @@ def main():
         ctx.set_partition(plan.offsets)
     if cfg.inner_prec == _abi.PREC_MULTILEVEL:
         ta = time.time()
-        levels = partition.partitioned_geometric_aggregates(pb.params, plan, a=args.agg_a)   # slab-respecting boxes
+        levels = partition.partitioned_geometric_aggregates(pb.params, plan, a=args.agg_a, min_coarse=args.min_coarse)   # slab-respecting boxes
         aggregates = partition.local_aggregates(levels, rank)
         log(f"aggregates: levels {[lv[1] for lv in levels]} in {time.time()-ta:.1f} s")
     solver.upload_problem(ctx, pb, cfg, aggregates)
