@@ -217,6 +217,9 @@ def main():
             "launches": spmv["launches"],
             "time_share_spmv_A": spmv["ms"] * 1e-3 / dt,
             "plain_csr_kernel_same_matrix": plain,
+            "note": ("frac = plain-CSR algorithmic bytes / time / peak (contract); it exceeds 1 because the kernel streams a "
+                     "3 B/nnz encoding of the matrix (16-bit window columns + 8-bit value codes): streamed_* and traffic "
+                     "are the bytes actually moved") if info["value_indexed"] else None,
         },
     }
 
