@@ -61,6 +61,7 @@ struct DevCsr {
   int64_t nrows = 0, ncols = 0, nnz = 0;  // local rows, global cols
   int64_t n_list = 0;                     // rows the kernel iterates over (== nrows unless sparse)
   bool sparse = false;
+  bool rep = false;  // replicated on every rank (coarse multigrid levels): never exchanges a halo
   int L = 64;
   int32_t n_local_cols = 0;               // columns < n_local_cols read x, others the halo
   int64_t *rp = nullptr;
@@ -125,6 +126,13 @@ struct MlLevel {
   double *dinv = nullptr;
   double lmax = 0;
   double *r = nullptr, *z = nullptr, *t = nullptr, *cd = nullptr, *cres = nullptr, *ctmp = nullptr;
+  // multi-rank: levels from alfd_ctx::ml_rep_level on are REPLICATED on every rank (global operators and
+  // vectors, no halo exchanges); gP / gR connect two replicated levels, P / R above stay rank-local
+  DevCsr gA, gC, gCt, gP, gR;
+  int64_t gn = 0, gnpad = 0, g_maxpiece = 0;
+  std::vector<int64_t> g_offs;  // rank offsets of this level's unknowns (size nranks + 1)
+  double *gdinv = nullptr, *gr = nullptr, *gz = nullptr, *gt = nullptr, *gcd = nullptr, *gcres = nullptr,
+         *gctmp = nullptr, *g_send = nullptr, *g_stage = nullptr;
 };
 
 enum State { ITERATE = 0, SUCCESS = 1, FAILURE = 2 };
@@ -198,6 +206,9 @@ struct alfd_ctx {
   std::vector<double> ml_wgt[ALFD_MAX_LEVELS];
   int64_t ml_ncoarse[ALFD_MAX_LEVELS] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<MlLevel> ml;
+  int ml_rep_level = -1;                      // first replicated level (multi-rank), -1: none
+  int64_t ml_rep_threshold = 300000;          // replicate levels with at most this many unknowns (ALFD_ML_REPLICATE)
+  double *g_w = nullptr, *g_tlam = nullptr;   // global W^-1 diagonal and multiplier work vector of the replicated levels
   std::vector<int64_t> ml_coff[ALFD_MAX_LEVELS];       // rank offsets of the coarse dofs of each level
   const int64_t *up_col_offsets = nullptr;             // upload_matrix overrides (level matrices)
   bool up_local_only = false;
@@ -571,7 +582,8 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
   if (!m.present) return ctx->err = "matrix not set", ALFD_E_NOT_SETUP;
   // RCCL send/recv pairs can be skipped by ranks with nothing to exchange; the
   // barrier-based in-process group needs every rank in every exchange.
-  if (ctx->nranks > 1 && (ctx->local || m.n_halo > 0 || m.send_off.back() > 0)) RC(halo_exchange(ctx, m, x));
+  if (ctx->nranks > 1 && !m.rep && (ctx->local || m.n_halo > 0 || m.send_off.back() > 0))
+    RC(halo_exchange(ctx, m, x));
   if (m.sparse && epi != 1) {
     // rows outside the list are structurally empty: their result is 0
     HIPC(hipMemsetAsync(y, 0, m.nrows * sizeof(double), ctx->stream));
@@ -1908,8 +1920,9 @@ static int power_iteration(alfd_ctx *ctx, int op) {
 // operators, so the preconditioner is a fixed SPD operator and plain CG applies.
 static void free_levels(alfd_ctx *ctx) {
   for (MlLevel &L : ctx->ml)
-    for (DevCsr *m : {&L.A, &L.C, &L.Ct, &L.P, &L.R}) csr_free(*m);
+    for (DevCsr *m : {&L.A, &L.C, &L.Ct, &L.P, &L.R, &L.gA, &L.gC, &L.gCt, &L.gP, &L.gR}) csr_free(*m);
   ctx->ml.clear();
+  ctx->ml_rep_level = -1;
 }
 
 static int download_csr(alfd_ctx *ctx, const DevCsr &m, HostCsr &h) {
@@ -2068,6 +2081,53 @@ static int level_cheb(alfd_ctx *ctx, int l, int degree, double ratio, const doub
   return ALFD_OK;
 }
 
+// ---- replicated levels: every rank holds the global operators and vectors and does the same work
+static int level_op_rep(alfd_ctx *ctx, int l, const double *x, double *y) {
+  MlLevel &L = ctx->ml[l];
+  RC(spmv_m(ctx, L.gA, ALFD_T_SPMV_OTHER, x, y, 0));
+  if (ctx->cfg.aug_assembled) return ALFD_OK;
+  RC(spmv_m(ctx, L.gC, ALFD_T_SPMV_OTHER, x, ctx->g_tlam, 2, 0.0, ctx->g_w));
+  return spmv_m(ctx, L.gCt, ALFD_T_SPMV_OTHER, ctx->g_tlam, y, 1, ctx->cfg.gamma);
+}
+
+static int level_cheb_rep(alfd_ctx *ctx, int l, int degree, double ratio, const double *r, double *z) {
+  MlLevel &L = ctx->ml[l];
+  const double lmax = L.lmax, lmin = lmax / ratio;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  VEC_LAUNCH(cheb_init_kernel, L.gnpad, degree > 1 ? 40 : 32, 1.0 / theta, L.gdinv, r, L.gcd, z, L.gcres,
+             degree > 1 ? 1 : 0);
+  for (int j = 1; j < degree; ++j) {
+    RC(level_op_rep(ctx, l, L.gcd, L.gctmp));
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    VEC_LAUNCH(cheb_step_kernel, L.gnpad, 64, c1, c2, L.gdinv, L.gctmp, L.gcres, L.gcd, z);
+    rho = rho_new;
+  }
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+static int ml_cycle_rep(alfd_ctx *ctx, int l, const double *r, double *z) {
+  const alfd_config &c = ctx->cfg;
+  const int last = (int)ctx->ml.size() - 1;
+  if (l == last) return level_cheb_rep(ctx, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  MlLevel &L = ctx->ml[l], &N = ctx->ml[l + 1];
+  RC(level_cheb_rep(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, r, z));
+  RC(level_op_rep(ctx, l, z, L.gt));
+  VEC_LAUNCH(sub_from_kernel, L.gnpad, 24, r, L.gt);
+  RC(spmv_m(ctx, N.gR, ALFD_T_SPMV_OTHER, L.gt, N.gr, 0));
+  RC(ml_cycle_rep(ctx, l + 1, N.gr, N.gz));
+  RC(spmv_m(ctx, N.gP, ALFD_T_SPMV_OTHER, N.gz, z, 1, 1.0));
+  RC(level_op_rep(ctx, l, z, L.gt));
+  VEC_LAUNCH(sub_from_kernel, L.gnpad, 24, r, L.gt);
+  RC(level_cheb_rep(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, L.gt, L.gr));
+  VEC_LAUNCH(axpy_kernel, L.gnpad, 24, (const double *)nullptr, 0, 1.0, L.gr, z);
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
 // z = V-cycle(r) on level l
 static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z) {
   const alfd_config &c = ctx->cfg;
@@ -2078,8 +2138,22 @@ static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z) {
   RC(level_op(ctx, l, z, L.t));
   VEC_LAUNCH(sub_from_kernel, L.npad, 24, r, L.t);                           // t = r - Aug z
   RC(spmv_m(ctx, N.R, ALFD_T_SPMV_OTHER, L.t, N.r, 0));                      // r_c = P^T t
-  RC(ml_cycle(ctx, l + 1, N.r, N.z));
-  RC(spmv_m(ctx, N.P, ALFD_T_SPMV_OTHER, N.z, z, 1, 1.0));                   // z += P e_c
+  if (l + 1 == ctx->ml_rep_level) {
+    // the restricted residual is gathered once; everything below runs replicated, without exchanges
+    HIPC(hipMemcpyAsync(N.g_send, N.r, N.n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    RC(comm_allgather(ctx, N.g_send, N.g_stage, (size_t)N.g_maxpiece * sizeof(double)));
+    for (int p = 0; p < ctx->nranks; ++p) {
+      const int64_t np = N.g_offs[p + 1] - N.g_offs[p];
+      if (np > 0)
+        HIPC(hipMemcpyAsync(N.gr + N.g_offs[p], N.g_stage + (int64_t)p * N.g_maxpiece, np * sizeof(double),
+                            hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    RC(ml_cycle_rep(ctx, l + 1, N.gr, N.gz));
+    RC(spmv_m(ctx, N.P, ALFD_T_SPMV_OTHER, N.gz + N.g_offs[ctx->rank], z, 1, 1.0));   // z += P e_c (my slice)
+  } else {
+    RC(ml_cycle(ctx, l + 1, N.r, N.z));
+    RC(spmv_m(ctx, N.P, ALFD_T_SPMV_OTHER, N.z, z, 1, 1.0));                 // z += P e_c
+  }
   RC(level_op(ctx, l, z, L.t));
   VEC_LAUNCH(sub_from_kernel, L.npad, 24, r, L.t);
   RC(level_cheb(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, L.t, L.r));   // post-smoothing correction
@@ -2123,6 +2197,94 @@ static int upload_level_part(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h, const
   return rc;
 }
 
+// All ranks contribute `bytes` bytes (sizes may differ); out = the contributions in rank order.
+static int allgather_bytes(alfd_ctx *ctx, const void *data, size_t bytes, std::vector<char> &out,
+                           std::vector<size_t> &sizes) {
+  const int P = ctx->nranks;
+  int64_t mine = (int64_t)bytes;
+  std::vector<int64_t> all(P);
+  int64_t *d_m = nullptr, *d_a = nullptr;
+  HIPC(hipMalloc((void **)&d_m, sizeof(int64_t)));
+  HIPC(hipMalloc((void **)&d_a, sizeof(int64_t) * P));
+  HIPC(hipMemcpyAsync(d_m, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+  int rc = comm_allgather(ctx, d_m, d_a, sizeof(int64_t));
+  if (rc == ALFD_OK) {
+    hipMemcpyAsync(all.data(), d_a, sizeof(int64_t) * P, hipMemcpyDeviceToHost, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+  }
+  hipFree(d_m);
+  hipFree(d_a);
+  if (rc != ALFD_OK) return rc;
+  size_t maxb = 8;
+  sizes.assign(P, 0);
+  for (int p = 0; p < P; ++p) {
+    sizes[p] = (size_t)all[p];
+    maxb = std::max(maxb, (sizes[p] + 7) / 8 * 8);
+  }
+  char *d_s = nullptr, *d_r = nullptr;
+  HIPC(hipMalloc((void **)&d_s, maxb));
+  HIPC(hipMalloc((void **)&d_r, maxb * P));
+  HIPC(hipMemsetAsync(d_s, 0, maxb, ctx->stream));
+  if (bytes) HIPC(hipMemcpyAsync(d_s, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  rc = comm_allgather(ctx, d_s, d_r, maxb);
+  std::vector<char> stage(maxb * P);
+  if (rc == ALFD_OK) {
+    hipMemcpyAsync(stage.data(), d_r, stage.size(), hipMemcpyDeviceToHost, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+  }
+  hipFree(d_s);
+  hipFree(d_r);
+  if (rc != ALFD_OK) return rc;
+  out.clear();
+  for (int p = 0; p < P; ++p) out.insert(out.end(), stage.begin() + p * maxb, stage.begin() + p * maxb + sizes[p]);
+  return ALFD_OK;
+}
+
+// Global CSR (rows of all ranks in rank order) from every rank's local rows.  shift: per-rank
+// amount added to the column ids of that rank's piece (rank-local ids -> global), or nullptr.
+static int gather_csr(alfd_ctx *ctx, const HostCsr &loc, const int64_t *shift, int64_t ncols_global, HostCsr &g) {
+  std::vector<int32_t> len(loc.nrows);
+  for (int64_t r = 0; r < loc.nrows; ++r) len[r] = (int32_t)(loc.rp[r + 1] - loc.rp[r]);
+  std::vector<char> blen, bcol, bval;
+  std::vector<size_t> slen, scol, sval;
+  RC(allgather_bytes(ctx, len.data(), len.size() * 4, blen, slen));
+  RC(allgather_bytes(ctx, loc.col.data(), (size_t)loc.nnz() * 4, bcol, scol));
+  RC(allgather_bytes(ctx, loc.val.data(), (size_t)loc.nnz() * 8, bval, sval));
+  const int64_t nrows = (int64_t)(blen.size() / 4), nnz = (int64_t)(bcol.size() / 4);
+  g.nrows = nrows;
+  g.ncols = ncols_global;
+  g.rp.assign(nrows + 1, 0);
+  const int32_t *gl = reinterpret_cast<const int32_t *>(blen.data());
+  for (int64_t r = 0; r < nrows; ++r) g.rp[r + 1] = g.rp[r] + gl[r];
+  g.col.resize(nnz);
+  g.val.resize(nnz);
+  std::memcpy(g.col.data(), bcol.data(), (size_t)nnz * 4);
+  std::memcpy(g.val.data(), bval.data(), (size_t)nnz * 8);
+  if (g.rp[nrows] != nnz) return ctx->err = "gather_csr: inconsistent pieces", ALFD_E_COMM;
+  if (shift) {
+    int64_t k = 0;
+    for (int p = 0; p < ctx->nranks; ++p) {
+      const int64_t np = (int64_t)(scol[p] / 4);
+      for (int64_t q = 0; q < np; ++q) g.col[k + q] = (int32_t)(g.col[k + q] + shift[p]);
+      k += np;
+    }
+  }
+  return ALFD_OK;
+}
+
+// device vector pieces (n_local each, rank order) -> global device vector on every rank
+static int gather_vec(alfd_ctx *ctx, const double *d_local, int64_t n_local, double *d_global) {
+  std::vector<double> h(n_local);
+  HIPC(hipMemcpyAsync(h.data(), d_local, n_local * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  std::vector<char> out;
+  std::vector<size_t> sizes;
+  RC(allgather_bytes(ctx, h.data(), h.size() * 8, out, sizes));
+  HIPC(hipMemcpyAsync(d_global, out.data(), out.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  return ALFD_OK;
+}
+
 static int ml_setup(alfd_ctx *ctx) {
   const alfd_config &c = ctx->cfg;
   if (c.ml_smooth_degree < 1 || c.ml_coarse_degree < 1 || !(c.ml_smooth_ratio > 1.0) || !(c.ml_coarse_ratio > 1.0))
@@ -2150,6 +2312,19 @@ static int ml_setup(alfd_ctx *ctx) {
       return ctx->err = "aggregates of level " + std::to_string(l) + " do not match this rank's unknowns", ALFD_E_INVALID;
   free_levels(ctx);
   ctx->ml.assign(nlev + 1, MlLevel());
+  // multi-rank: levels with few unknowns are replicated on every rank after the partitioned build
+  // (their kernels take microseconds, their halo exchanges would dominate)
+  int rep_from = -1;
+  if (ctx->nranks > 1 && ctx->ml_rep_threshold > 0)
+    for (int l = 1; l <= nlev; ++l)
+      if (off[l].back() <= ctx->ml_rep_threshold) {
+        rep_from = l;
+        break;
+      }
+  struct Stash {
+    HostCsr A, C, Ct, P, R;
+  };
+  std::vector<Stash> stash(nlev + 1);
   HostCsr A, C, Ct, An, Cn, Ctn, P, R;
   RC(download_csr(ctx, ctx->mat[ALFD_A], A));
   RC(download_csr(ctx, ctx->mat[ALFD_C], C));
@@ -2240,12 +2415,56 @@ static int ml_setup(alfd_ctx *ctx) {
     RC(upload_level_part(ctx, Nx.Ct, Ctn, ctx->nranks > 1 ? ctx->part[last].data() : nullptr, false));
     RC(upload_level_part(ctx, Nx.P, P, nullptr, true));
     RC(upload_level_part(ctx, Nx.R, R, nullptr, true));
+    if (rep_from > 0 && l + 1 >= rep_from) {
+      stash[l + 1].A = An;  // global column ids
+      stash[l + 1].C = Cn;
+      stash[l + 1].Ct = Ctn;
+      stash[l + 1].P = P;   // rank-local ids
+      stash[l + 1].R = R;
+    }
     // host copies of the new level in its LOCAL column space, for the next Galerkin step
     if (l + 1 < nlev) {
       RC(download_csr(ctx, Nx.A, A));
       RC(download_csr(ctx, Nx.C, C));
       RC(download_csr(ctx, Nx.Ct, Ct));
     }
+  }
+  if (rep_from > 0) {
+    // ---- replicate levels rep_from .. nlev: gather operators, diagonals and W on every rank
+    const int64_t lam_pad = pad_chunk(lam_global);
+    RC(ws_alloc_zero(ctx, &ctx->g_w, lam_pad));
+    RC(ws_alloc_zero(ctx, &ctx->g_tlam, lam_pad));
+    RC(gather_vec(ctx, ctx->diag[ALFD_INVW], ctx->n[last], ctx->g_w));
+    for (int l = rep_from; l <= nlev; ++l) {
+      MlLevel &L = ctx->ml[l];
+      L.g_offs = off[l];
+      L.gn = off[l].back();
+      L.gnpad = pad_chunk(L.gn);
+      HostCsr g;
+      RC(gather_csr(ctx, stash[l].A, nullptr, L.gn, g));
+      RC(upload_level_part(ctx, L.gA, g, nullptr, true));
+      RC(gather_csr(ctx, stash[l].C, nullptr, L.gn, g));
+      RC(upload_level_part(ctx, L.gC, g, nullptr, true));
+      RC(gather_csr(ctx, stash[l].Ct, nullptr, lam_global, g));
+      RC(upload_level_part(ctx, L.gCt, g, nullptr, true));
+      L.gA.rep = L.gC.rep = L.gCt.rep = true;
+      if (l > rep_from) {
+        RC(gather_csr(ctx, stash[l].P, off[l].data(), L.gn, g));        // n_{l-1} x n_l
+        RC(upload_level_part(ctx, L.gP, g, nullptr, true));
+        RC(gather_csr(ctx, stash[l].R, off[l - 1].data(), off[l - 1].back(), g));  // n_l x n_{l-1}
+        RC(upload_level_part(ctx, L.gR, g, nullptr, true));
+        L.gP.rep = L.gR.rep = true;
+      }
+      for (double **v : {&L.gdinv, &L.gr, &L.gz, &L.gt, &L.gcd, &L.gcres, &L.gctmp}) RC(ws_alloc_zero(ctx, v, L.gnpad));
+      RC(gather_vec(ctx, L.dinv, L.n, L.gdinv));
+      if (l == rep_from) {
+        for (int p = 0; p < ctx->nranks; ++p) L.g_maxpiece = std::max(L.g_maxpiece, off[l][p + 1] - off[l][p]);
+        L.g_maxpiece = std::max<int64_t>(L.g_maxpiece, 1);
+        RC(ws_alloc_zero(ctx, &L.g_send, L.g_maxpiece));
+        RC(ws_alloc_zero(ctx, &L.g_stage, L.g_maxpiece * ctx->nranks));
+      }
+    }
+    ctx->ml_rep_level = rep_from;
   }
   return ALFD_OK;
 }
@@ -2573,6 +2792,7 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW")) ctx->win_enable = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB")) ctx->win_RB = std::max(4, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
+  if (const char *e = std::getenv("ALFD_ML_REPLICATE")) ctx->ml_rep_threshold = std::atoll(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_LEVELS")) ctx->vi_levels = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_XCD")) ctx->vi_xcd = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_BATCHED")) ctx->vi_batched = std::atoi(e);

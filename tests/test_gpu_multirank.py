@@ -154,3 +154,26 @@ def test_partitioned_exact_w_inverse_matches_oracle_emulation(built):
         assert np.max(np.abs(out[r]["hist"] - ohist) / np.abs(ohist)) <= 1e-10
     for b in range(3):
         assert np.array_equal(np.concatenate([out[r]["rhs"][b] for r in range(world)]), orhs[b])
+
+
+def test_replicated_coarse_levels_change_nothing_but_the_exchanges(built, monkeypatch):
+    """Multi-rank multigrid: the levels below ALFD_ML_REPLICATE unknowns (default 300 k) are replicated on
+    every rank after the partitioned build (one all-gather of the restricted residual per V-cycle instead
+    of ~40 neighbour exchanges).  Row sums do not depend on the partition and the Chebyshev levels have no
+    reductions, so the residual history must be bit-identical to the fully partitioned hierarchy."""
+    world, n, ref = 3, 8, 0
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    cfg.inner.max_steps = 1000
+    cfg.inner_prec = _abi.PREC_MULTILEVEL
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
+    full = problems.stokes3d_sphere(n, ref)
+    plan = partition.slab_partition_stokes3d(n, ref, world)
+    levels = partition.partitioned_geometric_aggregates(full.params, plan, a=2, min_coarse=100)
+    _, rep = _run_ranks(world, n, ref, cfg, levels)                  # default: replicated below 300 k
+    monkeypatch.setenv("ALFD_ML_REPLICATE", "0")
+    _, part = _run_ranks(world, n, ref, cfg, levels)                 # fully partitioned hierarchy
+    for r in range(world):
+        assert rep[r]["res"]["inner_iterations"] == part[r]["res"]["inner_iterations"]
+        assert np.array_equal(rep[r]["hist"], part[r]["hist"])
+        for b in range(3):
+            assert np.array_equal(rep[r]["x"][b], part[r]["x"][b])
