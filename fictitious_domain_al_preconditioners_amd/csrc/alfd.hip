@@ -62,6 +62,7 @@ struct DevCsr {
   int64_t n_list = 0;                     // rows the kernel iterates over (== nrows unless sparse)
   bool sparse = false;
   bool rep = false;  // replicated on every rank (coarse multigrid levels): never exchanges a halo
+  bool derived = false;  // C / B built by the library as the transpose of an uploaded CT / BT
   int L = 64;
   int32_t n_local_cols = 0;               // columns < n_local_cols read x, others the halo
   int64_t *rp = nullptr;
@@ -322,16 +323,19 @@ static int comm_alltoallv(alfd_ctx *ctx, const void *sendbuf, const int64_t *sen
     return ALFD_OK;
   }
   if (ncclGroupStart() != ncclSuccess) return ctx->err = "ncclGroupStart", ALFD_E_COMM;
-  for (int p = 0; p < ctx->nranks; ++p) {
+  const char *failed = nullptr;  // the group is closed on every path: an open group would strand the peers
+  for (int p = 0; p < ctx->nranks && !failed; ++p) {
     const int64_t ns = send_off[p + 1] - send_off[p], nr = recv_off[p + 1] - recv_off[p];
     if (ns > 0 && ncclSend((const char *)sendbuf + (size_t)send_off[p] * es, (size_t)ns * es, ncclChar, p,
                            ctx->nccl, ctx->stream) != ncclSuccess)
-      return ctx->err = "ncclSend", ALFD_E_COMM;
-    if (nr > 0 && ncclRecv((char *)recvbuf + (size_t)recv_off[p] * es, (size_t)nr * es, ncclChar, p, ctx->nccl,
-                           ctx->stream) != ncclSuccess)
-      return ctx->err = "ncclRecv", ALFD_E_COMM;
+      failed = "ncclSend";
+    if (!failed && nr > 0 &&
+        ncclRecv((char *)recvbuf + (size_t)recv_off[p] * es, (size_t)nr * es, ncclChar, p, ctx->nccl,
+                 ctx->stream) != ncclSuccess)
+      failed = "ncclRecv";
   }
-  if (ncclGroupEnd() != ncclSuccess) return ctx->err = "ncclGroupEnd", ALFD_E_COMM;
+  if (ncclGroupEnd() != ncclSuccess && !failed) failed = "ncclGroupEnd";
+  if (failed) return ctx->err = failed, ALFD_E_COMM;
   return ALFD_OK;
 }
 
@@ -652,7 +656,7 @@ static int finish_dots(alfd_ctx *ctx, int64_t nb, int count, int out, int fin) {
 static int dot_async(alfd_ctx *ctx, int64_t npad, const double *x, const double *y, int out,
                      int fin = FIN_STORE) {
   const int64_t nb = npad / kChunk;
-  {
+  if (nb > 0) {
     Timer tm(ctx, ALFD_T_DOT, 16.0 * npad);
     hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream, x, y,
                        ctx->partial);
@@ -672,11 +676,15 @@ static int read_scalars(alfd_ctx *ctx, int first, int count) {
   return ALFD_OK;
 }
 
+// A rank may own zero rows of a block (e.g. the multiplier rows of a localised immersed body):
+// its vectors are empty and the launch is skipped; collectives are still entered by every rank.
 #define VEC_LAUNCH(kernel, npad, bytes_per_elem, ...)                                              \
   do {                                                                                             \
-    Timer tm__(ctx, ALFD_T_VEC, (double)(bytes_per_elem) * (double)(npad));                        \
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((npad) / kChunk)), dim3(kBlock), 0, ctx->stream,    \
-                       __VA_ARGS__);                                                               \
+    if ((npad) > 0) {                                                                              \
+      Timer tm__(ctx, ALFD_T_VEC, (double)(bytes_per_elem) * (double)(npad));                      \
+      hipLaunchKernelGGL(kernel, dim3((unsigned)((npad) / kChunk)), dim3(kBlock), 0, ctx->stream,  \
+                         __VA_ARGS__);                                                             \
+    }                                                                                              \
   } while (0)
 
 // ------------------------------------------------------------- operators
@@ -1120,7 +1128,7 @@ static int system_apply(alfd_ctx *ctx, const double *x, double *y) {
 // ---------------------------------------------------------------- FGMRES
 static int block_dots(alfd_ctx *ctx, const double *Vb, int count, const double *w, int out) {
   const int64_t N = ctx->ntot(), nb = N / kChunk;
-  {
+  if (nb > 0) {
     Timer tm(ctx, ALFD_T_DOT, 8.0 * N * (count + 1));
     hipLaunchKernelGGL(multi_dot_partial_kernel, dim3((unsigned)nb), dim3(kBlock), 0, ctx->stream, Vb, N,
                        count, w, ctx->partial, ctx->pstride);
@@ -1162,8 +1170,7 @@ static int fgmres(alfd_ctx *ctx, alfd_result *out) {
       if (c.orthogonalization == ALFD_ORTH_MGS) {
         for (int i = 0; i <= j; ++i) {
           RC(dot_async(ctx, N, Vj(i), wv, S_H + i));
-          hipLaunchKernelGGL(multi_axpy_neg_kernel, dim3((unsigned)(N / kChunk)), dim3(kBlock), 0,
-                             ctx->stream, Vj(i), N, 1, ctx->sc, (int)S_H + i, wv);
+          VEC_LAUNCH(multi_axpy_neg_kernel, N, 24, Vj(i), N, 1, ctx->sc, (int)S_H + i, wv);
         }
         RC(read_scalars(ctx, S_H, j + 1));
         for (int i = 0; i <= j; ++i) h[i] = ctx->sc_host[S_H + i];
@@ -1866,7 +1873,7 @@ static int diag_plus_m(alfd_ctx *ctx, const DevCsr &A, DevCsr &R, double g, int6
     hipLaunchKernelGGL(aug_diag_rows_kernel, dim3((unsigned)((R.n_list + 255) / 256)), dim3(256), 0,
                        ctx->stream, R.n_list, R.rp, R.col, R.val, R.sparse ? R.rows : nullptr,
                        ctx->diag[ALFD_INVW], R.halo, R.n_local_cols, ctx->s_aug);
-  hipLaunchKernelGGL(aug_diag_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+  hipLaunchKernelGGL(aug_diag_finish_kernel, dim3((unsigned)std::max<int64_t>(1, (n + 255) / 256)), dim3(256), 0, ctx->stream, n,
                      g, ctx->dA, ctx->s_aug, dinv);
   HIPC(hipGetLastError());
   return ALFD_OK;
@@ -1881,7 +1888,7 @@ static int power_iteration(alfd_ctx *ctx, int op) {
   HIPC(hipMemsetAsync(wv, 0, npad * sizeof(double), ctx->stream));
   auto fill = [&](int blk, double *dst) {
     const int64_t goff = ctx->nranks > 1 ? ctx->part[blk][ctx->rank] : 0;
-    hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((ctx->n[blk] + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)std::max<int64_t>(1, (ctx->n[blk] + 255) / 256)), dim3(256), 0,
                        ctx->stream, ctx->n[blk], goff, dst);
   };
   if (op == OP_AUG2) {
@@ -2606,7 +2613,7 @@ static int setup(alfd_ctx *ctx) {
         default: ALFD_DIAG(64); break;
       }
 #undef ALFD_DIAG
-      hipLaunchKernelGGL(inv_diag_kernel, dim3((unsigned)((ctx->n[0] + 255) / 256)), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL(inv_diag_kernel, dim3((unsigned)std::max<int64_t>(1, (ctx->n[0] + 255) / 256)), dim3(256), 0, ctx->stream,
                          ctx->n[0], ctx->dA, ctx->dinv_k);
     }
     if (cheb) RC(power_iteration(ctx, OP_K));
@@ -2916,12 +2923,19 @@ int alfd_set_matrix(alfd_ctx_t ctx, int slot, int64_t nrows, int64_t ncols, cons
     h.val.assign(val, val + nnz);
   }
   // single rank: the transposed operators are derived on upload, like
-  // transpose_operator(Ct) (stokes...:927); an explicit upload later overrides.
+  // transpose_operator(Ct) (stokes...:927), and re-derived whenever CT / BT is uploaded
+  // again (new values must not meet the transpose of the old ones); an explicit upload of
+  // C / B overrides and is then left alone.
+  if (slot == ALFD_C || slot == ALFD_B) ctx->mat[slot].derived = false;
   if (ctx->nranks == 1) {
-    if (slot == ALFD_CT && !ctx->mat[ALFD_C].present)
-      RC(upload_transpose(ctx, ALFD_C, nrows, ncols, row_ptr, col, val));
-    if (slot == ALFD_BT && !ctx->mat[ALFD_B].present)
-      RC(upload_transpose(ctx, ALFD_B, nrows, ncols, row_ptr, col, val));
+    const int pairs[2][2] = {{ALFD_CT, ALFD_C}, {ALFD_BT, ALFD_B}};
+    for (const auto &pr : pairs) {
+      const DevCsr &t = ctx->mat[pr[1]];
+      if (slot == pr[0] && (!t.present || t.derived)) {
+        RC(upload_transpose(ctx, pr[1], nrows, ncols, row_ptr, col, val));
+        ctx->mat[pr[1]].derived = true;
+      }
+    }
   }
   return ALFD_OK;
 }
@@ -3185,7 +3199,7 @@ int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launc
   double *dx = nullptr, *dy = nullptr;
   HIPC(hipMalloc((void **)&dx, std::max<int64_t>(m.ncols, 1) * sizeof(double)));
   HIPC(hipMalloc((void **)&dy, std::max<int64_t>(m.nrows, 1) * sizeof(double)));
-  hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((m.ncols + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)std::max<int64_t>(1, (m.ncols + 255) / 256)), dim3(256), 0, ctx->stream,
                      m.ncols, (int64_t)0, dx);
   const int was = ctx->timing;
   ctx->timing = 0;
@@ -3213,9 +3227,10 @@ int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value
                            double *streamed_bytes) {
   CHECK_CTX();
   if (slot < 0 || slot >= ALFD_NSLOTS || !ctx->mat[slot].present) return ALFD_E_INVALID;
+  const bool was_off = ctx->vi_off;
   ctx->vi_off = !use_value_index;
   const int rc = alfd_bench_spmv(ctx, slot, reps, ms_per_launch, nullptr);
-  ctx->vi_off = false;
+  ctx->vi_off = was_off;
   if (streamed_bytes) *streamed_bytes = ctx->mat[slot].streamed_bytes(use_value_index != 0);
   return rc;
 }
@@ -3315,6 +3330,15 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   out->algorithmic_bytes = m.algorithmic_bytes();
   out->streamed_bytes = m.streamed_bytes(true);
   return ALFD_OK;
+}
+
+int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value) {
+  if (!ctx || !name) return ALFD_E_INVALID;
+  if (std::strcmp(name, "value_index") == 0) {
+    ctx->vi_off = value == 0;
+    return ALFD_OK;
+  }
+  return ctx->err = std::string("unknown tunable ") + name, ALFD_E_INVALID;
 }
 
 int alfd_enable_timing(alfd_ctx_t ctx, int on) {

@@ -106,7 +106,8 @@ def config_from_prm(tree: dict) -> tuple[_abi.Config, dict]:
         if not cfg.grad_div_in_A:
             info["unsupported"].append("Grad-div stabilization = false (nested Bt Mp^-1 B in Aug)")
         if spd:
-            info["unsupported"].append("Diagonal SPD preconditioner = true needs MinRes (SURVEY 8(f) rank 3)")
+            # stokes...:1055-1064: the block-diagonal SPD preconditioner is used with SolverMinRes
+            cfg.outer_solver = _abi.OUTER_MINRES
         return cfg, info
     if top is not None:
         # immersed_laplace: Solver in {CG, ELMAN_triang, rational, augmented}
@@ -148,6 +149,12 @@ def config_from_prm(tree: dict) -> tuple[_abi.Config, dict]:
         info["solver"] = "modified AL" if modified else "ideal AL"
         info["beta_1"] = _f(ell.get("Beta_1"), 1.0)
         info["beta_2"] = _f(ell.get("Beta_2"), 10.0)
+        if "lambda background" in ell:
+            # elasticity.prm:25-28 (vector-valued variant; utilities.h:377-427): Lame parameters
+            info["elasticity"] = {"lambda_background": _f(ell.get("lambda background"), 2.0),
+                                  "mu_background": _f(ell.get("mu background"), 1.0),
+                                  "lambda_immersed": _f(ell.get("lambda immersed"), 20.0),
+                                  "mu_immersed": _f(ell.get("mu immersed"), 10.0)}
         info["diagonal_W"] = _b(al.get("Use diagonal inverse"), True)
         # parameter sanity of the reference (elliptic_interface.cc:874-884, 912-920)
         if modified and cfg.gamma2 > 20.0:

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan", "alfd_local_group_create",
     "alfd_local_group_destroy", "alfd_comm_init_local", "alfd_set_aggregates",
     "alfd_set_aggregate_partition", "alfd_get_matrix_info", "alfd_bench_spmv_format",
-    "alfd_host_window_plan",
+    "alfd_host_window_plan", "alfd_set_tunable",
 ]
 
 
@@ -94,6 +94,7 @@ def load_library():
         "alfd_get_matrix_info": (C.c_int, [vp, C.c_int, C.POINTER(_abi.MatrixInfo)]),
         "alfd_bench_spmv_format": (C.c_int, [vp, C.c_int, i32, C.c_int, C.POINTER(dbl), C.POINTER(dbl)]),
         "alfd_host_window_plan": (C.c_int, [i64, vp, vp, vp, i32, i32, C.POINTER(_abi.WindowPlanInfo)]),
+        "alfd_set_tunable": (C.c_int, [vp, C.c_char_p, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -222,8 +223,10 @@ class Context:
 
     def upload_rhs(self, rhs, x0=None):
         rhs = self._in(rhs)
-        x0b = _blocks(self._in(x0)) if x0 is not None else None
+        x0_arrs = self._in(x0) if x0 is not None else None   # kept alive across the call (may be copies)
+        x0b = _blocks(x0_arrs) if x0_arrs is not None else None
         self._ck(self._lib.alfd_upload_rhs(self._h, _blocks(rhs), x0b))
+        del x0_arrs
 
     def solve_resident(self, raise_on_failure=True):
         res = _abi.Result()
@@ -278,6 +281,10 @@ class Context:
         info = _abi.MatrixInfo()
         self._ck(self._lib.alfd_get_matrix_info(self._h, slot, C.byref(info)))
         return {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
+
+    def set_tunable(self, name, value):
+        """Run-time switch (alfd_set_tunable), e.g. ("value_index", 0): general-matrix SpMV kernel."""
+        self._ck(self._lib.alfd_set_tunable(self._h, name.encode(), int(value)))
 
     def enable_timing(self, on=True):
         self._ck(self._lib.alfd_enable_timing(self._h, int(on)))

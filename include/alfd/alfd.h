@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 6
+#define ALFD_ABI_VERSION 7
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -51,8 +51,11 @@ enum alfd_status {
  *         | stiffness_matrix_bg elliptic...:680]
  *   BT   [stokes_matrix.block(0,1) stokes...:924]   B [block(1,0) :925]
  *   CT   [coupling_matrix, n_u x n_lambda, stokes...:926, immersed_laplace.cc:640]
- *   C    optional; when absent alfd_setup() transposes CT (the reference applies
- *        transpose_operator(Ct), i.e. SparseMatrix::Tvmult -- stokes...:927)
+ *   C    optional (single rank): when it has not been uploaded explicitly, every
+ *        alfd_set_matrix(ALFD_CT) also stores the transpose as C (the reference applies
+ *        transpose_operator(Ct), i.e. SparseMatrix::Tvmult -- stokes...:927), so a
+ *        re-upload of CT with new values keeps C consistent.  Same for BT -> B.
+ *        Multi-rank: the C and B rows of a rank must be uploaded explicitly.
  *   M    [mass_matrix_immersed stokes...:928 | mass_matrix_fg elliptic...:682]
  *   MP   [preconditioner_matrix.block(1,1) stokes...:929]
  *   A2   [stiffness_matrix_fg elliptic...:681]
@@ -336,6 +339,12 @@ int alfd_host_window_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *
  * matrix through the 10 B/nnz window kernel); streamed_bytes as in alfd_matrix_info. */
 int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value_index,
                            double *ms_per_launch, double *streamed_bytes);
+/* Run-time switches of a context (measurement and A/B comparison; results never change):
+ *   "value_index"  1 (default): matrices whose row blocks were dictionary-coded at upload use the
+ *                  3 B/nnz kernel; 0: every windowed matrix goes through the general 10 B/nnz kernel
+ *                  (8-byte values + 16-bit window columns), as a matrix with unrelated values would.
+ * Returns ALFD_E_INVALID for an unknown name. */
+int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value);
 /* Kernel-class timing of the last solve, accumulated with HIP events when
  * alfd_enable_timing(ctx, 1) was called before: class ids in alfd_timing_class. */
 enum alfd_timing_class {

@@ -1388,6 +1388,15 @@ int orc_h_precond_apply(void *h, const alfd_control *inner_override, const doubl
   return rc;
 }
 
+int orc_h_system_apply(void *h, const double *const *src, double *const *dst) {
+  orc::Problem &P = *static_cast<orc::Problem *>(h);
+  std::vector<double> u, v(P.ntot(), 0.0);
+  pack(P, src, u);
+  const int rc = orc::system_apply(P, u.data(), v.data());
+  unpack(P, v, dst);
+  return rc;
+}
+
 int orc_precond_apply(const orc_problem *op, const alfd_config *cfg, const double *const *src,
                       double *const *dst, alfd_result *res) {
   orc::Problem P;

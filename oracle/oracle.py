@@ -63,6 +63,8 @@ def lib():
         l.orc_close.argtypes = [C.c_void_p]
         l.orc_h_precond_apply.restype = C.c_int
         l.orc_h_precond_apply.argtypes = [C.c_void_p, C.POINTER(_abi.Control), PP, PP, C.POINTER(_abi.Result)]
+        l.orc_h_system_apply.restype = C.c_int
+        l.orc_h_system_apply.argtypes = [C.c_void_p, PP, PP]
         l.orc_set_threads.restype = C.c_int
         l.orc_set_threads.argtypes = [C.c_int]
         l.orc_set_row_order.restype = C.c_int
@@ -174,6 +176,12 @@ class OracleSystem:
         rc = lib().orc_h_precond_apply(h, C.byref(inner) if inner is not None else None, _blocks(src),
                                        _blocks(dst), C.byref(res))
         return rc, dst, res
+
+    def handle_system_apply(self, h, src):
+        src = self._check(src)
+        dst = [np.zeros(n) for n in self.block_sizes]
+        rc = lib().orc_h_system_apply(h, _blocks(src), _blocks(dst))
+        return rc, dst
 
     @staticmethod
     def close_handle(h):

@@ -18,8 +18,8 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-def _run_ranks(world, n, ref, cfg, levels=None):
-    plan = partition.slab_partition_stokes3d(n, ref, world)
+def _run_ranks(world, n, ref, cfg, levels=None, plan=None):
+    plan = plan or partition.slab_partition_stokes3d(n, ref, world)
     group = solver.LocalGroup(world)
     out = [None] * world
     errs = []
@@ -177,3 +177,32 @@ def test_replicated_coarse_levels_change_nothing_but_the_exchanges(built, monkey
         assert np.array_equal(rep[r]["hist"], part[r]["hist"])
         for b in range(3):
             assert np.array_equal(rep[r]["x"][b], part[r]["x"][b])
+
+
+def test_rank_without_multiplier_rows(built):
+    """A geometric partition of a localised immersed body leaves some ranks without any multiplier
+    row (alfd_set_partition accepts empty ranges).  Such a rank launches nothing on its empty block
+    but still enters every collective; counts and history equal the oracle's emulation."""
+    world, n, ref = 3, 8, 0
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    cfg.inner.max_steps = 1000
+    plan = partition.slab_partition_stokes3d(n, ref, world)
+    nl = int(plan.offsets[-1][-1])
+    plan.offsets[-1] = np.array([0, 0, nl // 2, nl], np.int64)      # rank 0 owns no multiplier row
+    assert plan.local_sizes(0)[-1] == 0
+    plan, out = _run_ranks(world, n, ref, cfg, plan=plan)
+    full = problems.stokes3d_sphere(n, ref)
+    osys = oracle.system_from_problem(full, nranks_emulated=world, part_offsets=plan.offsets)
+    rc, orhs = osys.augment_rhs(cfg, cases.rhs_of(full))
+    rc, ox, ores, ohist = osys.solve(cfg, orhs)
+    assert rc == 0
+    for r in range(world):
+        res = out[r]["res"]
+        assert res["status"] == 0
+        assert (res["outer_iterations"], res["inner_iterations"], res["mp_iterations"]) == \
+            (ores.outer_iterations, ores.inner_iterations, ores.mp_iterations)
+        assert np.max(np.abs(out[r]["hist"] - ohist) / np.abs(ohist)) <= 1e-10
+    assert out[0]["x"][2].size == 0
+    for b in range(3):
+        xs = np.concatenate([out[r]["x"][b] for r in range(world)])
+        assert np.allclose(xs, ox[b], rtol=1e-9, atol=1e-10 * max(np.abs(ox[b]).max(), 1e-30))

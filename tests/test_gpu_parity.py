@@ -299,6 +299,43 @@ def test_error_behaviour(ctxs):
     fresh.close()
 
 
+def test_reupload_of_ct_rederives_the_transpose(built):
+    """The adapter uploads only CT / BT; C / B are derived.  Uploading a DIFFERENT CT (same sizes)
+    on the same context must not leave the transpose of the old one behind."""
+    pb, cfg = cases.case("stokes2d_circle")
+    ctx = solver.Context(0)
+    try:
+        def upload(scale):
+            ct = pb.mats["Ct"]
+            ct2 = problems.Csr(ct.nrows, ct.ncols, ct.row_ptr, ct.col, np.asarray(ct.val) * scale)
+            ctx.set_matrix(_abi.A, pb.mats["A"])
+            ctx.set_matrix(_abi.CT, ct2)                 # no explicit C, no explicit B
+            ctx.set_matrix(_abi.BT, pb.mats["Bt"])
+            ctx.set_matrix(_abi.MP, pb.mats["Mp"])
+            ctx.set_diag(_abi.INVW, pb.inv_w_diag_squared())
+            ctx.set_diag(_abi.MP_LUMPED_INV, pb.mp_lumped_inv())
+            ctx.configure(cfg)
+            ctx.setup(pb.block_sizes)
+            return ct2
+        src = cases.rng_blocks(pb, 3)
+        for scale in (1.0, 0.5):
+            ct2 = upload(scale)
+            mats = dict(pb.mats, Ct=ct2, C=ct2.transpose())
+            pb2 = problems.SyntheticProblem(params=pb.params, mats=mats, vecs=pb.vecs)
+            rc, ref = oracle.system_from_problem(pb2).system_apply(cfg, src)
+            assert rc == 0
+            for g, r in zip(ctx.system_apply(src), ref):
+                assert np.array_equal(g, r), scale
+        # an explicitly uploaded C is left alone by a later CT upload
+        ctx.set_matrix(_abi.C_, pb.mats["C"])
+        upload(0.5)
+        y = ctx.system_apply(src)
+        c_x = pb.mats["C"].to_scipy() @ src[0]
+        assert np.allclose(y[2], c_x, rtol=0, atol=1e-12 * np.abs(c_x).max())
+    finally:
+        ctx.close()
+
+
 def test_no_device_memory_growth_across_reupload_and_setup(built):
     """Re-uploading every slot and repeating alfd_setup (which rebuilds the multigrid
     hierarchy) must release the previous device arrays."""

@@ -100,11 +100,17 @@ def test_every_reference_prm_parses():
                 if os.path.getsize(path) == 0:
                     continue
                 tree = prm.parse_file(path)
-                if "elasticity" in f or "nitsche" in f:
-                    continue     # drivers outside the BASELINE configs
+                if "nitsche" in f:
+                    continue     # driver outside the BASELINE configs
                 cfg, info = prm.config_from_prm(tree)
                 assert cfg.outer.max_steps > 0 and info["driver"]
                 n += 1
     assert n >= 15
+    # BASELINE cfg 5: parameters_elliptic_interface/elasticity.prm (modified AL, exact W^-1, Lame 2,1 / 20,10)
+    cfg, info = prm.config_from_prm(prm.parse_file("/root/reference/parameters_elliptic_interface/elasticity.prm"))
+    assert cfg.variant == _abi.AL_ELL_MODIFIED and (cfg.gamma, cfg.gamma2) == (10.0, 1e-2)
+    assert cfg.w_inverse == _abi.W_MASS_INV_SQUARED and (cfg.outer.reduce, cfg.outer.tol) == (1e-6, 1e-10)
+    assert info["elasticity"] == {"lambda_background": 2.0, "mu_background": 1.0, "lambda_immersed": 20.0,
+                                  "mu_immersed": 10.0}
     cfg, info = prm.config_from_prm(prm.parse_file("/root/reference/parameters_stokes_3d.prm"))
     assert info["unsupported"] == [] and cfg.outer.tol == 1e-8 and cfg.inner.tol == 1e-2
