@@ -16,6 +16,10 @@
 //   Stokes:     A = (grad u, grad v) + gamma_gd (div u, div v)
 //               (stokes_immersed_boundary.cc:725-732), B = -(div u, q) with q in
 //               Q_{p-1}, Mp = pressure mass.
+//   elasticity: vector Q_1, A = lambda (div u, div v) + 2 mu (eps(u), eps(v))
+//               (ElasticityUtilities::assemble_elasticity, utilities.h:377-427); the immersed
+//               body is a 3-D box of Q1 hexahedra (elasticity.prm:55-57) carrying the jump
+//               operator A2 with (lambda_2 - lambda_1, mu_2 - mu_1) and a VOLUME coupling.
 //   immersed:   closed circle (P1 segments) in 2-D, cubed-sphere (Q1 quads) in
 //               3-D; Ct_{(j,b),(k,b)} = int_Gamma phi_j chi_k by Gauss
 //               quadrature on the immersed cells (the non-matching coupling of
@@ -230,6 +234,14 @@ struct Params {
   // also emit G_ij = int_Gamma phi_i phi_j on the background space (the particle-assembled
   // AL term of the "operator form", immersed_laplace.cc:659-705)
   int want_surface_mass = 0;
+  // linear elasticity (BASELINE cfg 5): background Lame parameters; lame2_* = the JUMP
+  // (immersed minus background) that A2 carries, as beta_2 - beta_1 does in the scalar case
+  // (elliptic_interface.cc:648-663).  immersed_kind 2: 3-D box [box_lo, box_hi] meshed with
+  // box_cells[0] x box_cells[1] x box_cells[2] trilinear cells.
+  int elasticity = 0;
+  double lame_lambda = 2.0, lame_mu = 1.0, lame2_lambda = 18.0, lame2_mu = 9.0;
+  double box_lo[3] = {-0.65, -0.3, -0.4}, box_hi[3] = {0.65, 0.3, 0.4};
+  int box_cells[3] = {2, 2, 2};
   // row ranges of this process (multi-GPU row partition); -1 = everything.
   // u/p ranges are in NODES (z-slabs of the lexicographic numbering), l in dofs.
   int64_t u_node0 = -1, u_node1 = -1, p_node0 = -1, p_node1 = -1, l0 = -1, l1 = -1;
@@ -344,6 +356,24 @@ void build_A(const Params &P, const Grid &g, Csr &A, int64_t node0, int64_t node
           if (nc == 1) {
             A.col[pos[0]] = (int32_t)jn;
             A.val[pos[0]++] = P.beta * lap;
+          } else if (P.elasticity) {
+            // lambda int d_a phi_i d_b phi_j + mu (delta_ab grad phi_i . grad phi_j + int d_b phi_i d_a phi_j)
+            for (int a = 0; a < nc; ++a)
+              for (int b = 0; b < nc; ++b) {
+                double tab = 1.0, tba = 1.0;
+                for (int c = 0; c < dim; ++c) {
+                  if (a == b) {
+                    tab *= (c == a) ? k[c] : m[c];
+                  } else {
+                    tab *= (c == a) ? gij[c] : (c == b) ? gji[c] : m[c];
+                    tba *= (c == b) ? gij[c] : (c == a) ? gji[c] : m[c];
+                  }
+                }
+                if (a == b) tba = tab;
+                const double v = P.lame_lambda * tab + P.lame_mu * ((a == b ? lap : 0.0) + tba);
+                A.col[pos[a]] = (int32_t)(jn * nc + b);
+                A.val[pos[a]++] = v;
+              }
           } else {
             for (int a = 0; a < nc; ++a)
               for (int b = 0; b < nc; ++b) {
@@ -756,6 +786,201 @@ void build_immersed(const Params &P, const Grid &g, Problem &pb) {
   pb.vecs["immersed_xyz"] = im.xyz;
 }
 
+// immersed_kind 2: the immersed body is an axis-aligned 3-D box meshed with trilinear cells
+// (elasticity.prm:56-57: hyper_rectangle).  Everything on it is a tensor-product operator, so
+// M, K and the elasticity jump operator A2 are written row by row from 1-D element matrices
+// (no Dirichlet rows on the immersed space); the volume coupling C_kj = int_{Omega_2} chi_k phi_j
+// is accumulated per immersed node over its adjacent cells (Gauss coupling_nq^3 per cell,
+// elliptic_interface.cc:572).  No triplet lists: the full-size instance has 4e5 cells.
+void build_immersed_box3d(const Params &P, const Grid &g, Problem &pb) {
+  const int nc = P.ncomp;
+  int n1[3];
+  double h[3];
+  Band1D M1[3], K1[3], G1[3];
+  for (int a = 0; a < 3; ++a) {
+    n1[a] = P.box_cells[a] + 1;
+    h[a] = (P.box_hi[a] - P.box_lo[a]) / P.box_cells[a];
+    M1[a] = band1d(1, 1, P.box_cells[a], h[a], 0);
+    K1[a] = band1d(1, 1, P.box_cells[a], h[a], 1);
+    G1[a] = band1d(1, 1, P.box_cells[a], h[a], 2);
+  }
+  const int64_t nl = (int64_t)n1[0] * n1[1] * n1[2];
+  auto split = [&](int64_t n, int *idx) {
+    idx[0] = (int)(n % n1[0]);
+    idx[1] = (int)((n / n1[0]) % n1[1]);
+    idx[2] = (int)(n / ((int64_t)n1[0] * n1[1]));
+  };
+  auto node = [&](const int *idx) { return ((int64_t)idx[2] * n1[1] + idx[1]) * n1[0] + idx[0]; };
+  // ---- M (expanded to nc components), K (scalar stiffness, expanded) and A2
+  Csr Mx, Kx, A2;
+  for (Csr *m : {&Mx, &Kx, &A2}) {
+    m->nrows = m->ncols = nl * nc;
+    m->row_ptr.assign(nl * nc + 1, 0);
+  }
+  const bool el = P.elasticity != 0;
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < nl; ++n) {
+    int idx[3];
+    split(n, idx);
+    const int64_t cnt = (int64_t)M1[0].count[idx[0]] * M1[1].count[idx[1]] * M1[2].count[idx[2]];
+    for (int a = 0; a < nc; ++a) {
+      Mx.row_ptr[n * nc + a + 1] = cnt;
+      Kx.row_ptr[n * nc + a + 1] = cnt;
+      A2.row_ptr[n * nc + a + 1] = el ? cnt * nc : cnt;
+    }
+  }
+  for (Csr *m : {&Mx, &Kx, &A2}) {
+    for (int64_t r = 0; r < nl * nc; ++r) m->row_ptr[r + 1] += m->row_ptr[r];
+    m->col.resize(m->row_ptr[nl * nc]);
+    m->val.resize(m->row_ptr[nl * nc]);
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < nl; ++n) {
+    int idx[3], j[3];
+    split(n, idx);
+    int64_t pm[3], pk[3], pa[3];
+    for (int a = 0; a < nc; ++a) {
+      pm[a] = Mx.row_ptr[n * nc + a];
+      pk[a] = Kx.row_ptr[n * nc + a];
+      pa[a] = A2.row_ptr[n * nc + a];
+    }
+    for (int k2 = 0; k2 < M1[2].count[idx[2]]; ++k2)
+      for (int k1 = 0; k1 < M1[1].count[idx[1]]; ++k1)
+        for (int k0 = 0; k0 < M1[0].count[idx[0]]; ++k0) {
+          j[0] = M1[0].first[idx[0]] + k0;
+          j[1] = M1[1].first[idx[1]] + k1;
+          j[2] = M1[2].first[idx[2]] + k2;
+          double m[3], k[3], gij[3], gji[3];
+          for (int a = 0; a < 3; ++a) {
+            m[a] = M1[a].at(idx[a], j[a]);
+            k[a] = K1[a].at(idx[a], j[a]);
+            gij[a] = G1[a].at(idx[a], j[a]);
+            gji[a] = G1[a].at(j[a], idx[a]);
+          }
+          const double mass = m[0] * m[1] * m[2];
+          const double lap = k[0] * m[1] * m[2] + m[0] * k[1] * m[2] + m[0] * m[1] * k[2];
+          const int64_t jn = node(j);
+          for (int a = 0; a < nc; ++a) {
+            Mx.col[pm[a]] = (int32_t)(jn * nc + a);
+            Mx.val[pm[a]++] = mass;
+            Kx.col[pk[a]] = (int32_t)(jn * nc + a);
+            Kx.val[pk[a]++] = lap;
+            if (!el) {
+              A2.col[pa[a]] = (int32_t)(jn * nc + a);
+              A2.val[pa[a]++] = P.beta2 * lap;
+              continue;
+            }
+            for (int b = 0; b < nc; ++b) {
+              double tab = 1.0, tba = 1.0;
+              for (int c = 0; c < 3; ++c) {
+                if (a == b) {
+                  tab *= (c == a) ? k[c] : m[c];
+                } else {
+                  tab *= (c == a) ? gij[c] : (c == b) ? gji[c] : m[c];
+                  tba *= (c == b) ? gij[c] : (c == a) ? gji[c] : m[c];
+                }
+              }
+              if (a == b) tba = tab;
+              A2.col[pa[a]] = (int32_t)(jn * nc + b);
+              A2.val[pa[a]++] = P.lame2_lambda * tab + P.lame2_mu * ((a == b ? lap : 0.0) + tba);
+            }
+          }
+        }
+  }
+  // ---- scalar coupling rows, one immersed node at a time
+  Gauss q(P.coupling_nq);
+  const int p = g.p;
+  std::vector<std::vector<std::pair<int64_t, double>>> rows(nl);
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t n = 0; n < nl; ++n) {
+    int idx[3];
+    split(n, idx);
+    std::vector<std::pair<int64_t, double>> acc;
+    for (int c2 = std::max(0, idx[2] - 1); c2 <= std::min(P.box_cells[2] - 1, idx[2]); ++c2)
+      for (int c1 = std::max(0, idx[1] - 1); c1 <= std::min(P.box_cells[1] - 1, idx[1]); ++c1)
+        for (int c0 = std::max(0, idx[0] - 1); c0 <= std::min(P.box_cells[0] - 1, idx[0]); ++c0) {
+          const int cell[3] = {c0, c1, c2};
+          for (size_t g0 = 0; g0 < q.x.size(); ++g0)
+            for (size_t g1 = 0; g1 < q.x.size(); ++g1)
+              for (size_t g2 = 0; g2 < q.x.size(); ++g2) {
+                const double t[3] = {q.x[g0], q.x[g1], q.x[g2]};
+                double chi = 1.0, x[3];
+                for (int a = 0; a < 3; ++a) {
+                  chi *= (idx[a] == cell[a]) ? 1 - t[a] : t[a];  // node sits at the low / high end of the cell
+                  x[a] = P.box_lo[a] + (cell[a] + t[a]) * h[a];
+                }
+                const double w = chi * q.w[g0] * q.w[g1] * q.w[g2] * h[0] * h[1] * h[2];
+                int bc[3];
+                double v1[3][3], d1[3][3];
+                for (int a = 0; a < 3; ++a) {
+                  const double sx = (x[a] - g.lo) / g.h;
+                  bc[a] = std::max(0, std::min(g.N - 1, (int)std::floor(sx)));
+                  shape1d(p, sx - bc[a], v1[a], d1[a]);
+                }
+                int l[3], jb[3];
+                for (l[2] = 0; l[2] <= p; ++l[2])
+                  for (l[1] = 0; l[1] <= p; ++l[1])
+                    for (l[0] = 0; l[0] <= p; ++l[0]) {
+                      for (int a = 0; a < 3; ++a) jb[a] = bc[a] * p + l[a];
+                      if (g.boundary(jb)) continue;
+                      acc.emplace_back(g.node(jb), v1[0][l[0]] * v1[1][l[1]] * v1[2][l[2]] * w);
+                    }
+              }
+        }
+    std::sort(acc.begin(), acc.end(), [](const auto &u, const auto &v) { return u.first < v.first; });
+    auto &row = rows[n];
+    for (size_t i = 0; i < acc.size();) {
+      size_t e = i;
+      double sum = 0;
+      while (e < acc.size() && acc[e].first == acc[i].first) sum += acc[e++].second;
+      row.emplace_back(acc[i].first, sum);
+      i = e;
+    }
+  }
+  Csr C;
+  C.nrows = nl * nc;
+  C.ncols = g.nnodes * nc;
+  C.row_ptr.assign(C.nrows + 1, 0);
+  for (int64_t n = 0; n < nl; ++n)
+    for (int b = 0; b < nc; ++b) C.row_ptr[n * nc + b + 1] = C.row_ptr[n * nc + b] + (int64_t)rows[n].size();
+  C.col.resize(C.row_ptr[C.nrows]);
+  C.val.resize(C.row_ptr[C.nrows]);
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < nl; ++n)
+    for (int b = 0; b < nc; ++b) {
+      int64_t pos = C.row_ptr[n * nc + b];
+      for (const auto &e : rows[n]) {
+        C.col[pos] = (int32_t)(e.first * nc + b);
+        C.val[pos++] = e.second;
+      }
+    }
+  rows.clear();
+  // g = embedded_value * int chi_k, f2 = (f_2 - f) int chi_k with f_2 - f = 1 (elasticity.prm:19-23);
+  // int chi_k is the row sum of the scalar mass matrix
+  std::vector<double> gv(nl * nc), f2(nl * nc), xyz(nl * 3);
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < nl; ++n) {
+    int idx[3];
+    split(n, idx);
+    double gi = 0.0;
+    for (int64_t k = Mx.row_ptr[n * nc]; k < Mx.row_ptr[n * nc + 1]; ++k) gi += Mx.val[k];
+    for (int b = 0; b < nc; ++b) {
+      gv[n * nc + b] = P.embedded_value[b] * gi;
+      f2[n * nc + b] = gi;
+    }
+    for (int a = 0; a < 3; ++a) xyz[n * 3 + a] = P.box_lo[a] + idx[a] * h[a];
+  }
+  pb.vecs["n_lambda_global"] = {(double)(nl * nc)};
+  pb.mats["Ct"] = csr_transpose(C);
+  pb.mats["C"] = std::move(C);
+  pb.mats["M"] = std::move(Mx);
+  pb.mats["K"] = std::move(Kx);
+  pb.mats["A2"] = std::move(A2);
+  pb.vecs["g"] = std::move(gv);
+  pb.vecs["f2"] = std::move(f2);
+  pb.vecs["immersed_xyz"] = std::move(xyz);
+}
+
 void build_rhs(const Params &P, const Grid &g, Problem &pb) {
   const int dim = g.dim, nc = P.ncomp;
   const Band1D M = band1d(g.p, g.p, g.N, g.h, 0);
@@ -787,6 +1012,18 @@ bool generate(Problem &pb) {
   if (P.coupling_nq < 1 || P.coupling_nq > 5) return pb.err = "coupling_nq in 1..5", false;
   if (P.immersed_kind == 1 && (P.dim != 2 || P.ncomp != 1 || P.imm_cells < 1 || !(P.imm_hi > P.imm_lo)))
     return pb.err = "box-immersed mode needs dim 2, ncomp 1, imm_cells >= 1, imm_hi > imm_lo", false;
+  if (P.immersed_kind == 2) {
+    if (P.dim != 3) return pb.err = "3-D box-immersed mode needs dim 3", false;
+    for (int a = 0; a < 3; ++a)
+      if (P.box_cells[a] < 1 || !(P.box_hi[a] > P.box_lo[a])) return pb.err = "bad immersed box", false;
+    int64_t nlx = P.ncomp;
+    for (int a = 0; a < 3; ++a) nlx *= P.box_cells[a] + 1;
+    if (nlx > 2147483647LL) return pb.err = "immersed space has more than 2^31-1 dofs", false;
+  }
+  if (P.elasticity && (P.ncomp != P.dim || P.dim != 3 || P.stokes || P.degree != 1))
+    return pb.err = "elasticity needs dim 3, degree 1, ncomp 3, stokes off", false;
+  if (P.u_node0 >= 0 && P.immersed_kind >= 1)
+    return pb.err = "row ranges are not implemented for the box-immersed (elliptic interface) problems", false;
   Grid g;
   g.dim = P.dim;
   g.p = P.degree;
@@ -836,7 +1073,10 @@ bool generate(Problem &pb) {
     pb.mats["Mp"] = std::move(Mp);
     pb.vecs["n_p_global"] = {(double)n_p};
   }
-  build_immersed(P, g, pb);
+  if (P.immersed_kind == 2)
+    build_immersed_box3d(P, g, pb);
+  else
+    build_immersed(P, g, pb);
   build_rhs(P, g, pb);
   return true;
 }
@@ -860,6 +1100,10 @@ struct alfd_synth_params {
   int32_t immersed_kind, imm_cells;
   double imm_lo, imm_hi, beta2;
   int32_t want_surface_mass, pad_;
+  int32_t elasticity, pad2_;
+  double lame_lambda, lame_mu, lame2_lambda, lame2_mu;
+  double box_lo[3], box_hi[3];
+  int32_t box_cells[3], pad3_;
 };
 
 void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
@@ -895,6 +1139,16 @@ void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
   P.imm_hi = sp->imm_hi;
   P.beta2 = sp->beta2;
   P.want_surface_mass = sp->want_surface_mass;
+  P.elasticity = sp->elasticity;
+  P.lame_lambda = sp->lame_lambda;
+  P.lame_mu = sp->lame_mu;
+  P.lame2_lambda = sp->lame2_lambda;
+  P.lame2_mu = sp->lame2_mu;
+  for (int i = 0; i < 3; ++i) {
+    P.box_lo[i] = sp->box_lo[i];
+    P.box_hi[i] = sp->box_hi[i];
+    P.box_cells[i] = sp->box_cells[i];
+  }
   if (!generate(*pb)) {
     if (err && errlen > 0) std::snprintf(err, errlen, "%s", pb->err.c_str());
     delete pb;

@@ -35,6 +35,11 @@ class _Params(C.Structure):
         ("immersed_kind", C.c_int32), ("imm_cells", C.c_int32),
         ("imm_lo", C.c_double), ("imm_hi", C.c_double), ("beta2", C.c_double),
         ("want_surface_mass", C.c_int32), ("pad_", C.c_int32),
+        ("elasticity", C.c_int32), ("pad2_", C.c_int32),
+        ("lame_lambda", C.c_double), ("lame_mu", C.c_double),
+        ("lame2_lambda", C.c_double), ("lame2_mu", C.c_double),
+        ("box_lo", C.c_double * 3), ("box_hi", C.c_double * 3),
+        ("box_cells", C.c_int32 * 3), ("pad3_", C.c_int32),
     ]
 
 
@@ -192,9 +197,13 @@ class SyntheticProblem:
 def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False, grad_div=False,
              gamma_grad_div=0.0, beta=1.0, center=(0.5, 0.5, 0.5), radius=0.2, immersed_refine=3,
              coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0),
-             row_ranges=None, immersed_box=None, beta2=0.0, surface_mass=False) -> SyntheticProblem:
+             row_ranges=None, immersed_box=None, beta2=0.0, surface_mass=False,
+             elasticity=None, immersed_box3d=None) -> SyntheticProblem:
     """immersed_box = (lo, hi, cells): the immersed domain is the 2-D box [lo,hi]^2
     with cells^2 Q1 cells (volume coupling, elliptic_interface); beta2 scales "A2".
+    elasticity = (lambda, mu, lambda_jump, mu_jump): vector-Q1 linear elasticity on the background
+    (utilities.h:377-427), A2 = the same form with the jump parameters on the immersed box;
+    immersed_box3d = (lo[3], hi[3], cells[3]): 3-D box meshed with trilinear cells (volume coupling).
     row_ranges = (u_node0, u_node1, p_node0, p_node1, l0, l1): generate only this
     rank's rows (node ranges for the background spaces, dof range for the
     multiplier); column indices stay global.  None = the whole problem."""
@@ -215,6 +224,15 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     if immersed_box is not None:
         p.immersed_kind, p.imm_lo, p.imm_hi, p.imm_cells = 1, float(immersed_box[0]), float(immersed_box[1]), int(immersed_box[2])
         p.beta2 = beta2
+    if immersed_box3d is not None:
+        p.immersed_kind = 2
+        for i in range(3):
+            p.box_lo[i], p.box_hi[i] = float(immersed_box3d[0][i]), float(immersed_box3d[1][i])
+            p.box_cells[i] = int(immersed_box3d[2][i])
+        p.beta2 = beta2
+    if elasticity is not None:
+        p.elasticity = 1
+        p.lame_lambda, p.lame_mu, p.lame2_lambda, p.lame2_mu = (float(v) for v in elasticity)
     err = C.create_string_buffer(256)
     h = lib.alfd_synth_generate(C.byref(p), err, 256)
     if not h:
@@ -301,6 +319,27 @@ def elliptic_interface2d(n_bg=64, n_fg=16, beta1=1.0, beta2=10.0, coupling_nq=3)
     return generate(dim=2, degree=1, ncomp=1, n_cells=n_bg, lo=-1.0, hi=1.0, beta=beta1,
                     coupling_nq=coupling_nq, body_force=(1.0,), embedded_value=(0.0,),
                     immersed_box=(-0.14, 0.47, n_fg), beta2=beta2 - beta1)
+
+
+def elasticity3d(n_bg=16, cells_fg=None, lame_bg=(2.0, 1.0), lame_fg=(20.0, 10.0), coupling_nq=2,
+                 box=((-0.65, -0.3, -0.4), (0.65, 0.3, 0.4))) -> SyntheticProblem:
+    """cfg 5: elliptic_interface 3-D elasticity, parameters_elliptic_interface/elasticity.prm.
+    Background vector-Q1 on n_bg^3 cells of [-1.25, 1.25]^3 (prm:55) with lambda, mu = 2, 1
+    (prm:25,27); immersed hyper_rectangle [-.65,.65] x [-.3,.3] x [-.4,.4] (prm:56-57) of trilinear
+    cells with lambda, mu = 20, 10 (prm:26,28): A = elasticity(lambda_1, mu_1) (utilities.h:377-427),
+    A2 = elasticity(lambda_2 - lambda_1, mu_2 - mu_1) on the box (the vector-valued analogue of
+    (beta_2 - beta_1)(grad, grad), elliptic_interface.cc:648-663), f = 1, f_2 - f = 1 per component
+    (prm:19-23).  cells_fg = None: the immersed cells are chosen no finer than the background.
+    The reference driver of this prm is missing from the tree (CMakeLists.txt:41), so the instance
+    is synthetic by necessity; coupling_nq defaults to 2 (the prm's 5 costs 15x the generation time)."""
+    h_bg = 2.5 / n_bg
+    if cells_fg is None:
+        cells_fg = tuple(max(1, int((box[1][i] - box[0][i]) / h_bg)) for i in range(3))
+    jump = (lame_fg[0] - lame_bg[0], lame_fg[1] - lame_bg[1])
+    return generate(dim=3, degree=1, ncomp=3, n_cells=n_bg, lo=-1.25, hi=1.25, coupling_nq=coupling_nq,
+                    body_force=(1.0, 1.0, 1.0), embedded_value=(0.0, 0.0, 0.0),
+                    elasticity=(lame_bg[0], lame_bg[1], jump[0], jump[1]),
+                    immersed_box3d=(box[0], box[1], cells_fg))
 
 
 def geometric_aggregates(pb: SyntheticProblem, a: int = 2, min_coarse: int = 600, max_levels: int = 7):

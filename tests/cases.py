@@ -130,6 +130,31 @@ def case(name):
             cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-10)
         cfg.inner_prec = _abi.PREC_MULTILEVEL
         cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
+    elif name in ("elasticity_modified", "elasticity_modified_multilevel"):
+        # BASELINE cfg 5: elliptic_interface 3-D elasticity, parameters_elliptic_interface/elasticity.prm,
+        # scaled down: modified AL (prm:43), gamma 10 / 1e-2 (prm:49-50), exact W^-1 = (M^-1)^2
+        # (`Use diagonal inverse = false`, prm:39), inner ReductionControl abs 1e-2 (prm:60-66), outer
+        # reduction 1e-6 (prm:77-84)
+        ml = name.endswith("multilevel")
+        pb = problems.elasticity3d(12 if ml else 8)
+        cfg = _abi.default_config(_abi.AL_ELL_MODIFIED)
+        cfg.gamma, cfg.gamma2 = 10.0, 1e-2
+        cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 10000, 1e-2, 1e-20)
+        cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-6)
+        if ml:      # diagonal W^-1 = 1/(M^2)_ii + the aggregation multigrid on the 3-component background
+            cfg.inner_prec = _abi.PREC_MULTILEVEL
+            cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
+        else:
+            cfg.w_inverse = _abi.W_MASS_INV_SQUARED
+    elif name == "stokes3d_bench_settings":
+        # exactly bench.py's solver settings (multigrid: Chebyshev(3) over [lmax/64, lmax], Chebyshev(10)
+        # coarsest solve, geometric aggregates a = 2 / min_coarse 600, inner cap 100 = prm:23) at small N
+        pb = problems.stokes3d_sphere(8, 1)
+        cfg = _abi.default_config(_abi.AL_STOKES)
+        cfg.inner_prec = _abi.PREC_MULTILEVEL
+        cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+        cfg.inner.max_steps = 100
+        return pb, cfg
     else:
         raise KeyError(name)
     cfg.inner.max_steps = max(cfg.inner.max_steps, 1000)
@@ -140,6 +165,8 @@ def aggregates_of(pb, cfg):
     """Aggregates handed to both the library and the oracle for ALFD_PREC_MULTILEVEL."""
     if cfg.inner_prec != _abi.PREC_MULTILEVEL:
         return None
+    if cfg.ml_coarse_degree == 10:      # stokes3d_bench_settings: bench.py's --agg-a 2 --min-coarse 600
+        return problems.geometric_aggregates(pb, a=2, min_coarse=600)
     return problems.geometric_aggregates(pb, a=2, min_coarse=100)
 
 
@@ -147,7 +174,8 @@ ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes
              "stokes3d_restart", "elliptic_modified", "elliptic_ideal", "elliptic_modified_jump1e3",
              "rational_minres", "stokes_minres_diag", "stokes3d_multilevel", "laplace3d_multilevel",
              "elliptic_modified_multilevel", "laplace2d_operator_form", "laplace2d_exact_w", "stokes2d_exact_w",
-             "laplace2d_operator_form_exact_w", "elliptic_modified_exact_w", "elliptic_ideal_exact_w"]
+             "laplace2d_operator_form_exact_w", "elliptic_modified_exact_w", "elliptic_ideal_exact_w",
+             "elasticity_modified", "elasticity_modified_multilevel", "stokes3d_bench_settings"]
 
 
 def oracle_system(pb, cfg):

@@ -141,3 +141,67 @@ def test_row_partitioned_generation_equals_slicing(n, ref, world):
         for v, b in (("f", 0), ("rhs_p", 1), ("g", 2)):
             o = plan.offsets[b]
             assert np.array_equal(loc.vecs[v], full.vecs[v][int(o[r]):int(o[r + 1])])
+
+
+def test_elasticity_operators_against_closed_forms():
+    """BASELINE cfg 5 (elasticity.prm; utilities.h:377-427): lambda (div, div) + 2 mu (eps, eps) on the
+    vector-Q1 background and, with the jump parameters, on the immersed box.  Independent checks:
+    Kronecker assembly of the background operator, rigid-body modes, strain energies of linear fields,
+    volume and coupling identities."""
+    n = 4
+    h = 2.5 / n
+    lam, mu = 2.0, 1.0
+    pb = problems.elasticity3d(n, cells_fg=(3, 2, 2))
+    M, K, G = _mats1d(1, 1, n, h)
+    n1 = n + 1
+    k3 = lambda a, b, c: sp.kron(c, sp.kron(b, a))   # x fastest
+    lap = k3(K, M, M) + k3(M, K, M) + k3(M, M, K)
+
+    def T(a, b):                                     # int d_a phi_i d_b phi_j
+        f = [M, M, M]
+        if a == b:
+            f[a] = K
+        else:
+            f[a], f[b] = G, G.T
+        return k3(*f)
+
+    nn = n1 ** 3
+    blocks = [[None] * 3 for _ in range(3)]
+    for a in range(3):
+        for b in range(3):
+            blocks[a][b] = lam * T(a, b) + mu * ((lap if a == b else 0 * lap) + T(b, a))
+    full = sp.bmat(blocks).tocsr()                   # component-major
+    perm = (np.arange(nn)[:, None] * 3 + np.arange(3)[None, :]).T.ravel()   # component-major -> node-major ids
+    P = sp.csr_matrix((np.ones(3 * nn), (perm, np.arange(3 * nn))), shape=(3 * nn, 3 * nn))
+    ref = (P @ full @ P.T).tolil()
+    idx = np.arange(nn)
+    c = np.stack([idx % n1, (idx // n1) % n1, idx // n1 ** 2], axis=1)
+    bnd = np.repeat(np.any((c == 0) | (c == n1 - 1), axis=1), 3)
+    keep = sp.diags((~bnd).astype(float))
+    ref = (keep @ ref.tocsr() @ keep + sp.diags(bnd.astype(float))).tocsr()
+    got = pb.mats["A"].to_scipy()
+    assert abs(got - ref).max() <= 1e-13 * abs(ref).max()
+    # immersed box: symmetric, rigid-body modes in the kernel, energies of a dilation and a shear
+    A2 = pb.mats["A2"].to_scipy()
+    xyz = pb.vecs["immersed_xyz"].reshape(-1, 3)
+    vol = 1.3 * 0.6 * 0.8
+    assert abs(A2 - A2.T).max() == 0.0
+    scale = abs(A2).max()
+    for b in range(3):
+        t = np.zeros_like(xyz)
+        t[:, b] = 1.0
+        assert np.abs(A2 @ t.ravel()).max() <= 1e-13 * scale
+    rot = np.stack([-xyz[:, 1], xyz[:, 0], 0 * xyz[:, 0]], axis=1).ravel()
+    assert np.abs(A2 @ rot).max() <= 1e-13 * scale
+    u = xyz.ravel()
+    assert abs(u @ (A2 @ u) - (9 * 18.0 + 6 * 9.0) * vol) <= 1e-11 * 216 * vol
+    u = np.stack([xyz[:, 1], 0 * xyz[:, 0], 0 * xyz[:, 0]], axis=1).ravel()
+    assert abs(u @ (A2 @ u) - 9.0 * vol) <= 1e-11 * 9 * vol
+    Mi = pb.mats["M"].to_scipy()
+    assert abs(Mi.sum() / 3 - vol) <= 1e-13
+    # the box lies inside the background: C applied to the constant field reproduces int chi_k
+    C = pb.mats["C"].to_scipy()
+    assert np.abs(C @ np.ones(C.shape[1]) - Mi @ np.ones(Mi.shape[0])).max() <= 1e-14
+    assert abs(C - pb.mats["Ct"].to_scipy().T).max() == 0.0
+    assert pb.block_sizes == [3 * nn, 3 * 4 * 3 * 3, 3 * 4 * 3 * 3]
+    assert np.allclose(pb.vecs["f2"], Mi @ np.ones(Mi.shape[0]))
