@@ -88,7 +88,6 @@ class WindowPlanInfo(C.Structure):
         ("blocks", C.c_int64), ("fallback_blocks", C.c_int64), ("segments", C.c_int64),
         ("value_indexed_blocks", C.c_int64), ("value_indexed_nnz", C.c_int64), ("value_wide_nnz", C.c_int64),
         ("dictionary_entries", C.c_int64), ("batches", C.c_int64), ("decode_mismatches", C.c_int64),
-        ("packed", C.c_int64),
     ]
 
 

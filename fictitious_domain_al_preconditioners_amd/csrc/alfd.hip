@@ -89,8 +89,6 @@ struct DevCsr {
   double *dict = nullptr;
   int64_t vi_blocks = 0, vi_nnz = 0, vi_dict_total = 0, vi_wide_nnz = 0;
   uint16_t *vidw = nullptr;  // 16-bit value codes of the blocks with 257..512 distinct values
-  uint8_t *pk_code = nullptr;   // lane-major packed value codes / LDS column offsets (spmv_window_vit_kernel)
-  uint16_t *pk_col = nullptr;
   uint64_t *vib_tab = nullptr;  // class-sorted row batches per block (spmv_window_vib_kernel)
   int32_t *vib_cnt = nullptr;
   int32_t vib_stride = 0;
@@ -247,7 +245,6 @@ struct alfd_ctx {
   int vi_levels = 1;                        // also dictionary-code multigrid level matrices
                         // waves per workgroup of the class-batched kernel (4 or 8)
   int vi_batched = 1;                       // class-batched VI kernel (ALFD_SPMV_VI_BATCHED=0: in-order batches)
-  int vi_packed = 1;                        // lane-major packed streams + spmv_window_vit_kernel (ALFD_SPMV_VI_PACKED=0: vib kernel)
   int win_RB_vi = 96;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
   int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
@@ -473,28 +470,6 @@ static void launch_window(alfd_ctx *ctx, const DevCsr &m, const double *x, doubl
                      lds, ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin,   \
                      m.blk_W, m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->win_xcd)
   const bool vi = m.vi && !ctx->vi_off;
-  if (vi && ctx->vi_batched && m.vib_tab && m.pk_code && ctx->vi_packed == 1) {
-    const size_t lds_vit = (size_t)(m.win_maxW + kVitDictSlots) * sizeof(double);
-#define ALFD_VIT(EPI, TAG)                                                                                    \
-  hipLaunchKernelGGL((spmv_window_vit_kernel<EPI, TAG>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds_vit, \
-                     ctx->stream, m.nrows, m.win_RB, m.rp, m.col, m.lcol, m.val, m.blk_seg_begin, m.blk_W,    \
-                     m.seg_col, m.seg_off, x, m.halo, m.n_local_cols, y, alpha, d, y2, m.vidx, m.vidw,        \
-                     m.blk_dict_off, m.blk_dict_n, m.dict, m.pk_code, m.pk_col, m.vib_tab, m.vib_cnt,         \
-                     m.vib_stride)
-    if (m.tag == 0) {
-      if (epi == 0) ALFD_VIT(0, 0);
-      else if (epi == 1) ALFD_VIT(1, 0);
-      else if (epi == 2) ALFD_VIT(2, 0);
-      else ALFD_VIT(3, 0);
-    } else {
-      if (epi == 0) ALFD_VIT(0, 1);
-      else if (epi == 1) ALFD_VIT(1, 1);
-      else if (epi == 2) ALFD_VIT(2, 1);
-      else ALFD_VIT(3, 1);
-    }
-#undef ALFD_VIT
-    return;
-  }
   if (vi && ctx->vi_batched && m.vib_tab) {
 #define ALFD_VIB(EPI, TAG)                                                                                    \
   hipLaunchKernelGGL((spmv_window_vib_kernel<EPI, TAG>), dim3((unsigned)m.win_nblocks), dim3(kBlock), lds,   \
@@ -1439,7 +1414,7 @@ static void host_halo_plan(int64_t nnz, const int32_t *col, const int64_t *col_o
 // alfd_host_window_plan so that CPU tests can decode and check it), then upload.
 struct WindowParams {
   int RB_long = 96, short_scale = 2, RB_vi = 96, maxW = 4096, gap = 8;
-  bool want_vi = true, want_pack = true;
+  bool want_vi = true;
 };
 struct WindowPlan {
   bool win = false, vi = false;
@@ -1456,8 +1431,6 @@ struct WindowPlan {
   std::vector<uint64_t> tab;
   std::vector<int32_t> cnt;
   int stride = 0;
-  std::vector<uint8_t> pk_code;   // lane-major packed streams of the class-batched rows (mode-0 blocks)
-  std::vector<uint16_t> pk_col;
 };
 static int window_row_block(const WindowParams &wp, int L) {
   // short rows: larger row blocks, so a window serves about as many entries as for L = 64
@@ -1659,34 +1632,6 @@ static void plan_window(int64_t nrows, int L, const int64_t *rp, const int32_t *
       }
     });
   for (auto &x : th2) x.join();
-  if (!wp.want_pack || maxW > (65535 - kVitXOff) / 8) return;
-  // lane-major packed streams (spmv_window_vit_kernel): per row of class c = ceil(len / 64) the
-  // entry 64 j + l moves to slot (c - 1) l + min(l, rem) + j, rem = len - 64 (c - 1); rows the
-  // packed code path does not serve (other block modes, class 0 or > kVibMaxClass) keep their order
-  pl.pk_code.assign((size_t)nnz + 16, 0);
-  pl.pk_col.assign((size_t)nnz + 16, 0);
-  std::vector<std::thread> th3;
-  for (int t = 0; t < T; ++t)
-    th3.emplace_back([&, t]() {
-      for (int64_t b = nb * t / T; b < nb * (t + 1) / T; ++b) {
-        const int64_t r0 = b * RB, r1 = std::min<int64_t>(r0 + RB, nrows);
-        const bool packed = pl.blkW[b] >= 0 && pl.blk_dn[b] >= 0 && !(pl.blk_dn[b] & kDictWide);
-        for (int64_t r = r0; r < r1; ++r) {
-          const int64_t k0 = rp[r], len = rp[r + 1] - rp[r];
-          const int64_t c = (len + 63) / 64, rem = len - 64 * (c - 1);
-          for (int64_t e = 0; e < len; ++e) {
-            int64_t q = e;
-            if (packed && c >= 1 && c <= kVibMaxClass) {
-              const int64_t l = e & 63, j = e >> 6;
-              q = (c - 1) * l + std::min(l, rem) + j;
-            }
-            pl.pk_code[k0 + q] = pl.vidx[k0 + e];
-            pl.pk_col[k0 + q] = (uint16_t)(pl.blkW[b] >= 0 ? kVitXOff + 8 * (int)pl.lcol[k0 + e] : 0);
-          }
-        }
-      }
-    });
-  for (auto &x : th3) x.join();
 }
 
 template <class T>
@@ -1705,7 +1650,6 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
   wp.maxW = ctx->win_maxW;
   wp.gap = ctx->win_gap;
   wp.want_vi = ctx->win_vi && (slot_is_user || ctx->vi_levels);
-  wp.want_pack = ctx->vi_packed != 0;
   WindowPlan pl;
   plan_window(m.nrows, m.L, rp, col, val, wp, pl);
   if (!pl.win) return ALFD_OK;
@@ -1731,10 +1675,6 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
     RC(upload_vec(ctx, m, &m.vib_tab, pl.tab));
     RC(upload_vec(ctx, m, &m.vib_cnt, pl.cnt));
     m.vib_stride = pl.stride;
-  }
-  if (!pl.pk_code.empty()) {
-    RC(upload_vec(ctx, m, &m.pk_code, pl.pk_code));
-    RC(upload_vec(ctx, m, &m.pk_col, pl.pk_col));
   }
   HIPC(hipStreamSynchronize(ctx->stream));
   m.vi = true;
@@ -2863,7 +2803,6 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_VI_LEVELS")) ctx->vi_levels = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_XCD")) ctx->vi_xcd = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_BATCHED")) ctx->vi_batched = std::atoi(e);
-  if (const char *e = std::getenv("ALFD_SPMV_VI_PACKED")) ctx->vi_packed = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB_VI")) ctx->win_RB_vi = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_R")) ctx->vi_rows_R = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_J")) ctx->vi_rows_J = std::atoi(e);
@@ -3341,22 +3280,6 @@ int alfd_host_window_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
         if (code >= nd || std::memcmp(&pl.dict[pl.doff[b] + code], &val[k], 8) != 0) ++bad;
       }
     }
-    if (!pl.pk_code.empty() && W >= 0 && pl.blk_dn[b] >= 0 && !(pl.blk_dn[b] & kDictWide)) {
-      // lane-major packed streams: what lane l of the kernel reads as its j-th entry must be entry 64 j + l
-      for (int64_t r = r0; r < r1; ++r) {
-        const int64_t kr = rp[r], len = rp[r + 1] - rp[r];
-        const int64_t c = (len + 63) / 64, rem = len - 64 * (c - 1);
-        if (c < 1 || c > kVibMaxClass) continue;
-        for (int64_t l = 0; l < 64; ++l)
-          for (int64_t j = 0; j < c; ++j) {
-            const int64_t e = 64 * j + l;
-            if (e >= len) continue;
-            const int64_t q = (c - 1) * l + std::min(l, rem) + j;
-            bad += q >= len || pl.pk_code[kr + q] != pl.vidx[kr + e] ||
-                   pl.pk_col[kr + q] != (uint16_t)(kVitXOff + 8 * (int)pl.lcol[kr + e]);
-          }
-      }
-    }
     if (pl.stride > 0) {
       seen.assign(r1 - r0, 0);
       batches += pl.cnt[b];
@@ -3384,7 +3307,6 @@ int alfd_host_window_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
       for (int v : seen) bad += v != 1;
     }
   }
-  out->packed = pl.pk_code.empty() ? 0 : 1;
   out->batches = batches;
   out->decode_mismatches = bad;
   return ALFD_OK;
@@ -3414,10 +3336,6 @@ int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value) {
   if (!ctx || !name) return ALFD_E_INVALID;
   if (std::strcmp(name, "value_index") == 0) {
     ctx->vi_off = value == 0;
-    return ALFD_OK;
-  }
-  if (std::strcmp(name, "packed") == 0) {  // lane-major packed kernel (1) or the class-batched one (0)
-    if (ctx->vi_packed != 0) ctx->vi_packed = value ? 1 : 2;
     return ALFD_OK;
   }
   return ctx->err = std::string("unknown tunable ") + name, ALFD_E_INVALID;

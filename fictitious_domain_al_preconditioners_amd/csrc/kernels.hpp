@@ -758,179 +758,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 }
 
 // --------------------------------------------------------------------------
-// Lane-major packed variant of the class-batched kernel (the default for value-indexed
-// matrices).  Measured on MI355X (profiles/r02): the class-batched kernel above is not
-// HBM-bound but bound by the NUMBER of vector-memory instructions -- two narrow loads (one
-// byte, two bytes per lane) per 64-entry chunk -- and by the dependent chain behind them.
-// The stream is therefore re-laid out at upload, per row, in LANE-MAJOR order: the c entries
-// k0 + l, k0 + l + 64, ... that the canonical order gives lane l sit next to each other
-// (lanes below rem = len - 64 (c - 1) hold c entries, the others c - 1, so a row still
-// occupies exactly its len slots).  One unaligned dword / dwordx2 load then fetches all value
-// codes of a lane and one dword / dwordx2 / dwordx3 load all its window columns: 2 loads per
-// row instead of 2 c.  The columns are stored as LDS byte offsets (kVitXOff + 8 * window
-// column; the dictionary sits in front of the window at LDS byte 0), so a gather address is
-// the unpacked field itself.  Lane assignment and fma order are the canonical ones: the
-// result is bit-identical to every other SpMV kernel.
-constexpr int kVitDictSlots = kDictMaxEntries;   // LDS doubles reserved in front of the x window
-constexpr int kVitXOff = kVitDictSlots * 8;      // LDS byte offset of the x window
-
-template <int N>
-__device__ __forceinline__ void vit_load(const uint8_t *__restrict__ p, uint32_t (&w)[N]) {
-  __builtin_memcpy(w, p, 4 * N);  // any byte alignment: gfx950 global loads are alignment-free
-}
-
-// Batch of 4 rows with exactly NCH chunks each (only the last chunk may be partial).
-template <int NCH>
-__device__ __forceinline__ void vit_rows(const uint32_t (&ks)[4], const int32_t (&len)[4], int lane,
-                                         const uint8_t *__restrict__ pk_code_b,
-                                         const uint16_t *__restrict__ pk_col_b, const char *lds,
-                                         double (&acc)[4]) {
-  constexpr int CW = NCH <= 4 ? 1 : 2, XW = (NCH + 1) / 2;
-  uint32_t cw[4][CW], xw[4][XW];
-  bool ok[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rem = len[i] - 64 * (NCH - 1);   // entries of the last chunk, 1..64
-    ok[i] = lane < rem;
-    const uint32_t q = ks[i] + (uint32_t)((NCH - 1) * lane + (lane < rem ? lane : rem));
-    vit_load<CW>(pk_code_b + q, cw[i]);
-    vit_load<XW>(reinterpret_cast<const uint8_t *>(pk_col_b + q), xw[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    double xv[NCH], v[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const uint32_t code = (cw[i][j / 4] >> (8 * (j % 4))) & 0xffu;
-      const uint32_t xo = (xw[i][j / 2] >> (16 * (j % 2))) & 0xffffu;
-      xv[j] = *reinterpret_cast<const double *>(lds + xo);
-      v[j] = *reinterpret_cast<const double *>(lds + code * 8u);
-    }
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) asm volatile("" : "+v"(xv[j]), "+v"(v[j]));
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      if (j == NCH - 1) {
-        if (ok[i]) acc[i] = fma(v[j], xv[j], acc[i]);
-      } else {
-        acc[i] = fma(v[j], xv[j], acc[i]);
-      }
-    }
-  }
-}
-
-template <int EPI, int TAG = 0>
-__global__ __launch_bounds__(256) void spmv_window_vit_kernel(
-    int64_t nrows, int32_t RB, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
-    const uint16_t *__restrict__ lcol, const double *__restrict__ val,
-    const int32_t *__restrict__ blk_seg_begin, const int32_t *__restrict__ blk_W,
-    const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
-    const double *__restrict__ x, const double *__restrict__ x_halo, int32_t n_local,
-    double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2,
-    const uint8_t *__restrict__ vidx, const uint16_t *__restrict__ vidw,
-    const int32_t *__restrict__ blk_dict_off, const int32_t *__restrict__ blk_dict_n,
-    const double *__restrict__ dict, const uint8_t *__restrict__ pk_code,
-    const uint16_t *__restrict__ pk_col, const uint64_t *__restrict__ btab,
-    const int32_t *__restrict__ bcnt, int32_t bstride) {
-  extern __shared__ double lds_d[];
-  double *ds = lds_d;                   // block dictionary: doubles [0, kVitDictSlots)
-  double *xs = lds_d + kVitDictSlots;   // x window behind it
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t b = blockIdx.x;
-  const int32_t W = blk_W[b];
-  int mode = 2;  // block-uniform (see vi_rows)
-  if (W >= 0) {
-    const int32_t nd = blk_dict_n[b];
-    mode = nd < 0 ? 1 : ((nd & kDictWide) ? 3 : 0);
-    const int32_t ndv = nd & 0xffff;
-    if (nd >= 0)
-      for (int t = threadIdx.x; t < ndv; t += 256) ds[t] = dict[blk_dict_off[b] + t];
-    const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
-    for (int32_t s = s0 + wave; s < s1; s += 4) {
-      const int32_t c0 = seg_col[s], o0 = seg_off[s];
-      const int32_t len = ((s + 1 < s1) ? seg_off[s + 1] : W) - o0;
-      for (int32_t i = lane; i < len; i += 64) {
-        const int32_t c = c0 + i;
-        xs[o0 + i] = (c < n_local) ? x[c] : x_halo[c - n_local];
-      }
-    }
-    __syncthreads();
-  }
-  const int64_t row_begin = b * RB;
-  const int64_t k_blk = rp[row_begin];
-  const uint16_t *lcol_b = lcol + k_blk;
-  const uint8_t *vidx_b = vidx + k_blk;
-  const uint16_t *vidw_b = vidw + k_blk;
-  const int32_t *col_b = col + k_blk;
-  const double *val_b = val + k_blk;
-  const uint8_t *pk_code_b = pk_code + k_blk;
-  const uint16_t *pk_col_b = pk_col + k_blk;
-  const char *lds = reinterpret_cast<const char *>(lds_d);
-  const int32_t nbatch = bcnt[b];
-  const uint64_t *bt = btab + (b * bstride + wave) * 4;
-  uint64_t nx[4] = {0, 0, 0, 0};
-  if (wave < nbatch) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) nx[i] = bt[i];
-  }
-  for (int32_t bi = wave; bi < nbatch; bi += 4) {
-    uint64_t desc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) desc[i] = nx[i];
-    bt += 16;
-    if (bi + 4 < nbatch) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) nx[i] = bt[i];
-    }
-    const int cls = (int)(desc[0] >> 56);
-    uint32_t ks[4];
-    int32_t len[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ks[i] = (uint32_t)desc[i];
-      len[i] = (int32_t)((desc[i] >> 32) & 0xffff);
-    }
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (mode == 0) {
-      switch (cls) {
-        case 0: break;
-        case 1: vit_rows<1>(ks, len, lane, pk_code_b, pk_col_b, lds, acc); break;
-        case 2: vit_rows<2>(ks, len, lane, pk_code_b, pk_col_b, lds, acc); break;
-        case 3: vit_rows<3>(ks, len, lane, pk_code_b, pk_col_b, lds, acc); break;
-        case 4: vit_rows<4>(ks, len, lane, pk_code_b, pk_col_b, lds, acc); break;
-        case 5: vit_rows<5>(ks, len, lane, pk_code_b, pk_col_b, lds, acc); break;
-        case 6: vit_rows<6>(ks, len, lane, pk_code_b, pk_col_b, lds, acc); break;
-        default: vi_rows<4, 2, 0>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
-      }
-    } else if (mode == 3) {
-      vi_rows<4, 2, 3>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
-    } else if (mode == 1) {
-      vi_rows<4, 2, 1>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
-    } else {
-      vi_rows<4, 2, 2>(ks, len, lane, lcol_b, vidx_b, vidw_b, col_b, val_b, xs, ds, x, x_halo, n_local, acc);
-    }
-    const double s = reduce_rows4(acc[0], acc[1], acc[2], acc[3]);
-    const int q = lane >> 4;  // 16-lane row q holds the tree of batch row {0, 2, 1, 3}[q]
-    const uint64_t dq = q == 0 ? desc[0] : (q == 1 ? desc[2] : (q == 2 ? desc[1] : desc[3]));
-    const int id = (int)((dq >> 48) & 0xff);
-    if ((lane & 15) == 0 && id != 0xff) {
-      const int64_t r = row_begin + id;
-      if (EPI == 0)
-        y[r] = s;
-      else if (EPI == 1)
-        y[r] = fma(alpha, s, y[r]);
-      else if (EPI == 2)
-        y[r] = d[r] * s;
-      else {
-        y[r] = s;
-        y2[r] = d[r] * s;
-      }
-    }
-  }
-}
-
-// --------------------------------------------------------------------------
 // The same LDS-window scheme for short-row matrices (canonical L = 8, 16 or 32:
 // Q1 stencils, pressure mass, multigrid level operators).  An L-lane group plays
 // the role of the wave: it owns a batch of R consecutive rows of the block and

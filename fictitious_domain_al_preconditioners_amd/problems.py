@@ -322,19 +322,22 @@ def elliptic_interface2d(n_bg=64, n_fg=16, beta1=1.0, beta2=10.0, coupling_nq=3)
 
 
 def elasticity3d(n_bg=16, cells_fg=None, lame_bg=(2.0, 1.0), lame_fg=(20.0, 10.0), coupling_nq=2,
-                 box=((-0.65, -0.3, -0.4), (0.65, 0.3, 0.4))) -> SyntheticProblem:
+                 box=((-0.65, -0.3, -0.4), (0.65, 0.3, 0.4)), mesh_ratio=2.0) -> SyntheticProblem:
     """cfg 5: elliptic_interface 3-D elasticity, parameters_elliptic_interface/elasticity.prm.
     Background vector-Q1 on n_bg^3 cells of [-1.25, 1.25]^3 (prm:55) with lambda, mu = 2, 1
     (prm:25,27); immersed hyper_rectangle [-.65,.65] x [-.3,.3] x [-.4,.4] (prm:56-57) of trilinear
     cells with lambda, mu = 20, 10 (prm:26,28): A = elasticity(lambda_1, mu_1) (utilities.h:377-427),
     A2 = elasticity(lambda_2 - lambda_1, mu_2 - mu_1) on the box (the vector-valued analogue of
     (beta_2 - beta_1)(grad, grad), elliptic_interface.cc:648-663), f = 1, f_2 - f = 1 per component
-    (prm:19-23).  cells_fg = None: the immersed cells are chosen no finer than the background.
+    (prm:19-23).  cells_fg = None: immersed cells of about mesh_ratio x the background cell size -- the
+    prm itself pairs 4^3 background cells of 0.625 with ONE immersed cell of 1.3 x 0.6 x 0.8 (prm:100-104);
+    with h_fg ~ h_bg the distributed multiplier loses inf-sup stability and the outer iteration count
+    grows with refinement (12 -> 25 -> 397 outer iterations at n_bg = 16 -> 32 -> 96, measured).
     The reference driver of this prm is missing from the tree (CMakeLists.txt:41), so the instance
     is synthetic by necessity; coupling_nq defaults to 2 (the prm's 5 costs 15x the generation time)."""
-    h_bg = 2.5 / n_bg
+    h_fg = 2.5 / n_bg * mesh_ratio
     if cells_fg is None:
-        cells_fg = tuple(max(1, int((box[1][i] - box[0][i]) / h_bg)) for i in range(3))
+        cells_fg = tuple(max(1, int(round((box[1][i] - box[0][i]) / h_fg))) for i in range(3))
     jump = (lame_fg[0] - lame_bg[0], lame_fg[1] - lame_bg[1])
     return generate(dim=3, degree=1, ncomp=3, n_cells=n_bg, lo=-1.25, hi=1.25, coupling_nq=coupling_nq,
                     body_force=(1.0, 1.0, 1.0), embedded_value=(0.0, 0.0, 0.0),

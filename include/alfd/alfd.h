@@ -332,7 +332,6 @@ typedef struct alfd_window_plan_info {
   int64_t blocks, fallback_blocks, segments;
   int64_t value_indexed_blocks, value_indexed_nnz, value_wide_nnz, dictionary_entries;
   int64_t batches, decode_mismatches;
-  int64_t packed;   /* 1: lane-major packed streams were built (and decode back) */
 } alfd_window_plan_info;
 int alfd_host_window_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
                           int32_t lanes, int32_t want_value_index, alfd_window_plan_info *out);
@@ -341,8 +340,6 @@ int alfd_host_window_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *
 int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value_index,
                            double *ms_per_launch, double *streamed_bytes);
 /* Run-time switches of a context (measurement and A/B comparison; results never change):
- *   "packed"       1 (default): value-indexed matrices use the lane-major packed kernel
- *                  (spmv_window_vit_kernel); 0: the class-batched kernel of round 1.
  *   "value_index"  1 (default): matrices whose row blocks were dictionary-coded at upload use the
  *                  3 B/nnz kernel; 0: every windowed matrix goes through the general 10 B/nnz kernel
  *                  (8-byte values + 16-bit window columns), as a matrix with unrelated values would.

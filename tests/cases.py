@@ -136,7 +136,7 @@ def case(name):
         # (`Use diagonal inverse = false`, prm:39), inner ReductionControl abs 1e-2 (prm:60-66), outer
         # reduction 1e-6 (prm:77-84)
         ml = name.endswith("multilevel")
-        pb = problems.elasticity3d(12 if ml else 8)
+        pb = problems.elasticity3d(16 if ml else 10)
         cfg = _abi.default_config(_abi.AL_ELL_MODIFIED)
         cfg.gamma, cfg.gamma2 = 10.0, 1e-2
         cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 10000, 1e-2, 1e-20)

@@ -46,7 +46,7 @@ def test_version_strerror_and_default_config_mirror():
     assert (c.restart, c.inner.max_steps, c.inner.tol, c.inner.kind) == (30, 100, 1e-2, _abi.CTRL_ABS)
     assert _abi.default_config(_abi.AL_ELL_MODIFIED).restart == 50
     assert C.sizeof(_abi.Config) == 240 and C.sizeof(_abi.Result) == 80
-    assert C.sizeof(_abi.MatrixInfo) == 88 and C.sizeof(_abi.WindowPlanInfo) == 96
+    assert C.sizeof(_abi.MatrixInfo) == 88 and C.sizeof(_abi.WindowPlanInfo) == 88
 
 
 def test_argument_validation_without_gpu():
@@ -92,7 +92,6 @@ def test_host_window_plan_decodes_back():
     assert info["windowed"] and info["value_indexed"] and info["decode_mismatches"] == 0
     assert info["row_block"] == 96 and info["blocks"] == -(-a.nrows // 96)
     assert info["value_indexed_nnz"] == a.nnz and info["value_wide_nnz"] == 0 and info["batches"] > 0
-    assert info["packed"] == 1
     assert info["dictionary_entries"] <= 256 * info["blocks"]
     rng = np.random.default_rng(3)
     # 16-bit codes: every value scaled by one of 9 factors
