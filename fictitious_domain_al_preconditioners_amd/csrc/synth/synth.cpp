@@ -29,6 +29,8 @@
 // This file is product-side input tooling: bench.py, the tests and the oracle
 // all consume its output. It contains no solver arithmetic.
 
+#include "synth.h"
+
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -1086,25 +1088,6 @@ bool generate(Problem &pb) {
 // ------------------------------------------------------------------- C API
 extern "C" {
 
-struct alfd_synth_params {
-  int32_t dim, degree, ncomp, n_cells;
-  double lo, hi;
-  int32_t stokes, grad_div;
-  double gamma_grad_div, beta;
-  double center[3];
-  double radius;
-  int32_t immersed_refine, coupling_nq;
-  double body_force[3];
-  double embedded_value[3];
-  int64_t u_node0, u_node1, p_node0, p_node1, l0, l1;
-  int32_t immersed_kind, imm_cells;
-  double imm_lo, imm_hi, beta2;
-  int32_t want_surface_mass, pad_;
-  int32_t elasticity, pad2_;
-  double lame_lambda, lame_mu, lame2_lambda, lame2_mu;
-  double box_lo[3], box_hi[3];
-  int32_t box_cells[3], pad3_;
-};
 
 void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
   Problem *pb = new Problem;

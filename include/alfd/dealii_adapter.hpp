@@ -17,6 +17,10 @@
 //     SolverFGMRES<BlockVector<double>> solver(sys);        // solve(AA, x, b, P)
 //     solver.solve(sys.system_operator(), solution_block, system_rhs_block, P);
 //     outer_solver_control.last_step()  ->  solver.last_step()
+// The other call sites map the same way: elliptic_interface.cc:900-906 / 940-948 ->
+// EllipticInterfacePreconditioners::BlockTriangularALPreconditioner{,Modified} + SolverFGMRES;
+// immersed_laplace.cc:625-631 -> RationalPreconditioner + SolverMinRes (tests/adapter/adapter_demo.cpp
+// runs all three against the golden iteration counts).
 //
 // It is templated on the matrix / vector types and needs only the members the
 // reference uses: SparseMatrix: m(), n(), n_nonzero_elements(), begin(row) /
@@ -96,7 +100,35 @@ class System {
     check(alfd_set_diag(ctx_, slot, (int64_t)d.size(), &*d.begin()));
   }
 
-  void configure(const alfd_config &cfg) {
+  // Aggregates of the multilevel inner preconditioner (ALFD_PREC_MULTILEVEL; replaces the ML
+  // aggregation of utilities.h:304-317).  weights may be empty (constant modes).
+  void set_aggregates(int level, const std::vector<int32_t> &agg, int64_t n_coarse,
+                      const std::vector<double> &weights = {}) {
+    check(alfd_set_aggregates(ctx_, level, (int64_t)agg.size(), agg.data(), weights.empty() ? nullptr : weights.data(),
+                              n_coarse));
+  }
+  // `Use diagonal inverse = false` / `Diagonal mass immersed = false` (immersed_laplace.cc:859-877,
+  // stokes...:979-985, elliptic_interface.cc:713-737): the exact W^-1 = (M^-1)^2 (mode
+  // ALFD_W_MASS_INV_SQUARED) or M^-1 (ALFD_W_MASS_INV) from the immersed mass matrix; applied to the
+  // config passed to configure() afterwards.
+  template <class SparseMatrixType>
+  void set_w_inverse(int mode, const SparseMatrixType &mass_matrix) {
+    set_matrix(ALFD_M, mass_matrix);
+    w_inverse_ = mode;
+  }
+  // multi-GPU: one System per rank (alfd.h: alfd_comm_init / alfd_set_partition), before any set_matrix
+  void comm_init(int rank, int nranks, const void *unique_id, size_t bytes) {
+    check(alfd_comm_init(ctx_, rank, nranks, unique_id, bytes));
+  }
+  void set_partition(const std::vector<std::vector<int64_t>> &offsets) {
+    std::vector<const int64_t *> p;
+    for (const auto &o : offsets) p.push_back(o.data());
+    check(alfd_set_partition(ctx_, (int)p.size(), p.data()));
+  }
+
+  void configure(const alfd_config &cfg_in) {
+    alfd_config cfg = cfg_in;
+    if (w_inverse_ >= 0) cfg.w_inverse = w_inverse_;
     cfg_ = cfg;
     check(alfd_configure(ctx_, &cfg));
   }
@@ -152,6 +184,7 @@ class System {
  private:
   alfd_ctx_t ctx_ = nullptr;
   alfd_config cfg_{};
+  int w_inverse_ = -1;
   friend class SystemOperator;
 };
 
@@ -185,12 +218,25 @@ using BlockPreconditionerAugmentedLagrangian = ALPreconditioner<ALFD_AL2>;
 using BlockPreconditionerAugmentedLagrangianStokes = ALPreconditioner<ALFD_AL_STOKES>;
 using BlockPreconditionerAugmentedLagrangianDiagonal = ALPreconditioner<ALFD_AL_STOKES_DIAG>;
 
-// Depth-2 drop-in for SolverFGMRES<BlockVector<double>> (stokes...:1067-1074):
-// the whole solve runs on the GPU; the stop rule is alfd_config::outer.
-template <class BlockVectorType>
-class SolverFGMRES {
+// rational_preconditioner.h:12-99 (used with SolverMinRes, immersed_laplace.cc:625-631)
+using RationalPreconditioner = ALPreconditioner<ALFD_RATIONAL>;
+// augmented_lagrangian_preconditioner.h:115-164 and :168-238 live in this namespace in the reference
+namespace EllipticInterfacePreconditioners {
+using BlockTriangularALPreconditioner = ALPreconditioner<ALFD_AL_ELL_IDEAL>;
+using BlockTriangularALPreconditionerModified = ALPreconditioner<ALFD_AL_ELL_MODIFIED>;
+}  // namespace EllipticInterfacePreconditioners
+
+// Depth-2 drop-ins for SolverFGMRES<BlockVector<double>> (stokes...:1067-1074,
+// elliptic_interface.cc:862-906) and SolverMinRes<BlockVector<double>> (immersed_laplace.cc:629-631,
+// stokes...:1057-1064): the whole solve runs on the GPU; the stop rule is alfd_config::outer and the
+// Krylov method alfd_config::outer_solver, which must match the class used.
+template <class BlockVectorType, int OuterSolver>
+class GpuKrylovSolver {
  public:
-  explicit SolverFGMRES(System &s) : sys_(&s) {}
+  explicit GpuKrylovSolver(System &s) : sys_(&s) {
+    if (s.config().outer_solver != OuterSolver)
+      throw Error(ALFD_E_INVALID, "alfd_config::outer_solver does not match this solver class");
+  }
   template <class MatrixType, class PreconditionerType>
   void solve(const MatrixType &A, BlockVectorType &x, const BlockVectorType &b, const PreconditionerType &P) {
     if (A.system() != sys_ || P.system() != sys_)
@@ -208,6 +254,10 @@ class SolverFGMRES {
   System *sys_;
   alfd_result last_{};
 };
+template <class BlockVectorType>
+using SolverFGMRES = GpuKrylovSolver<BlockVectorType, ALFD_OUTER_FGMRES>;
+template <class BlockVectorType>
+using SolverMinRes = GpuKrylovSolver<BlockVectorType, ALFD_OUTER_MINRES>;
 
 }  // namespace dealii_adapter
 }  // namespace alfd

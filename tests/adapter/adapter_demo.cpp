@@ -1,7 +1,13 @@
-// Drives include/alfd/dealii_adapter.hpp the way immersed_laplace.cc:636-949
-// drives deal.II: operators from (mock) SparseMatrix objects, W^-1 = 1/M_ii^2,
-// rhs augmentation, BlockPreconditionerAugmentedLagrangian + SolverFGMRES.
-// Prints "outer=<n> inner=<n>"; exit code 3 if no GPU context can be created.
+// Drives include/alfd/dealii_adapter.hpp the way the reference's solve() functions drive deal.II:
+//   (default)  immersed_laplace.cc:636-949: operators from (mock) SparseMatrix objects, W^-1 = 1/M_ii^2,
+//              rhs augmentation, BlockPreconditionerAugmentedLagrangian + SolverFGMRES
+//   elliptic   elliptic_interface.cc:680-906: EllipticInterfacePreconditioners::
+//              BlockTriangularALPreconditionerModified + SolverFGMRES (restart 50), W^-1 = 1/(M^2)_ii
+//   rational   immersed_laplace.cc:585-631: RationalPreconditioner + SolverMinRes
+//   export F   dump the default system to the .alfd wire format (no GPU)
+// Prints "outer=<n> inner=<n> ..."; exit code 3 if no GPU context can be created.
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -11,25 +17,7 @@
 #include "alfd/dealii_export.hpp"
 #include "mock_dealii.hpp"
 
-extern "C" {
-struct alfd_synth_params {
-  int32_t dim, degree, ncomp, n_cells;
-  double lo, hi;
-  int32_t stokes, grad_div;
-  double gamma_grad_div, beta;
-  double center[3];
-  double radius;
-  int32_t immersed_refine, coupling_nq;
-  double body_force[3];
-  double embedded_value[3];
-  int64_t u_node0, u_node1, p_node0, p_node1, l0, l1;
-};
-void *alfd_synth_generate(const alfd_synth_params *, char *, int);
-void alfd_synth_free(void *);
-int alfd_synth_matrix(void *, const char *, int64_t *, int64_t *, int64_t *, const int64_t **, const int32_t **,
-                      const double **);
-int alfd_synth_vector(void *, const char *, int64_t *, const double **);
-}
+#include "../../fictitious_domain_al_preconditioners_amd/csrc/synth/synth.h"
 
 static mock::SparseMatrix load(void *h, const char *name) {
   int64_t m, n, nnz;
@@ -40,14 +28,139 @@ static mock::SparseMatrix load(void *h, const char *name) {
   return mock::SparseMatrix((size_t)m, (size_t)n, (const long *)rp, col, val);
 }
 
-int main(int argc, char **argv) {
+static void base_params(alfd_synth_params &sp) {
+  std::memset(&sp, 0, sizeof(sp));
+  sp.u_node0 = sp.u_node1 = sp.p_node0 = sp.p_node1 = sp.l0 = sp.l1 = -1;
+  sp.beta = 1;
+}
+
+// elliptic_interface.cc:680-906 with parameters_modified.prm (the `elliptic_modified` test case)
+static int run_elliptic() {
   using namespace alfd::dealii_adapter;
   alfd_synth_params sp;
-  std::memset(&sp, 0, sizeof(sp));
-  sp.dim = 2, sp.degree = 1, sp.ncomp = 1, sp.n_cells = 64, sp.lo = 0, sp.hi = 1, sp.beta = 1;
+  base_params(sp);
+  sp.dim = 2, sp.degree = 1, sp.ncomp = 1, sp.n_cells = 64, sp.lo = -1, sp.hi = 1, sp.coupling_nq = 3;
+  sp.body_force[0] = 1.0;
+  sp.immersed_kind = 1, sp.imm_lo = -0.14, sp.imm_hi = 0.47, sp.imm_cells = 16, sp.beta2 = 10.0 - 1.0;
+  char err[256];
+  void *h = alfd_synth_generate(&sp, err, 256);
+  if (!h) return std::fprintf(stderr, "generator: %s\n", err), 2;
+  mock::SparseMatrix stiffness_matrix_bg = load(h, "A"), stiffness_matrix_fg = load(h, "A2"),
+                     coupling_matrix = load(h, "Ct"), mass_matrix_fg = load(h, "M");
+  const size_t n_bg = stiffness_matrix_bg.m(), n_fg = mass_matrix_fg.m();
+  // compute_inverse_diagonal_mass_squared (utilities.h:348-374): 1 / (M M)_ii = 1 / sum_k M_ik M_ki
+  mock::Vector inverse_diag_mass_squared(n_fg);
+  for (size_t i = 0; i < n_fg; ++i) {
+    double d = 0;
+    for (auto it = mass_matrix_fg.begin(i); it != mass_matrix_fg.end(i); ++it) d += it->value() * it->value();
+    inverse_diag_mass_squared[i] = 1. / d;
+  }
+  System gpu(0);
+  gpu.set_matrix(ALFD_A, stiffness_matrix_bg);      // elliptic_interface.cc:680
+  gpu.set_matrix(ALFD_A2, stiffness_matrix_fg);     // :681
+  gpu.set_matrix(ALFD_M, mass_matrix_fg);           // :682
+  gpu.set_matrix(ALFD_CT, coupling_matrix);         // :683-687 (C = transpose_operator(Ct) is derived)
+  gpu.set_diag(ALFD_INVW, inverse_diag_mass_squared);
+  alfd_config cfg;
+  alfd_default_config(&cfg, ALFD_AL_ELL_MODIFIED);
+  cfg.gamma = 10, cfg.gamma2 = 1e-2;                // parameters_modified.prm:48-49
+  cfg.inner = {ALFD_CTRL_REDUCTION, 100000, 1e-2, 1e-20};
+  cfg.outer = {ALFD_CTRL_REDUCTION, 1000, 1e-10, 1e-10};
+  gpu.configure(cfg);
+  gpu.setup();
+  mock::BlockVector system_solution_block({n_bg, n_fg, n_fg}), system_rhs_block({n_bg, n_fg, n_fg});
+  int64_t n;
+  const double *f, *f2;
+  alfd_synth_vector(h, "f", &n, &f);
+  for (size_t i = 0; i < n_bg; ++i) system_rhs_block.block(0)[i] = f[i];
+  alfd_synth_vector(h, "f2", &n, &f2);
+  for (size_t i = 0; i < n_fg; ++i) system_rhs_block.block(1)[i] = f2[i];   // block 2 stays 0 (:903)
+  auto system_operator = gpu.system_operator();
+  EllipticInterfacePreconditioners::BlockTriangularALPreconditionerModified preconditioner_AL(gpu);
+  SolverFGMRES<mock::BlockVector> solver_fgmres(gpu);   // elliptic_interface.cc:862-865 (max_basis_size 50 = cfg.restart)
+  solver_fgmres.solve(system_operator, system_solution_block, system_rhs_block, preconditioner_AL);   // :905-906
+  std::printf("outer=%u inner=%lld residual=%.6e\n", solver_fgmres.last_step(),
+              (long long)solver_fgmres.last_result().inner_iterations, solver_fgmres.last_value());
+  alfd_synth_free(h);
+  return 0;
+}
+
+// immersed_laplace.cc:585-631: the "rational" branch (the `rational_minres` test case)
+static int run_rational() {
+  using namespace alfd::dealii_adapter;
+  alfd_synth_params sp;
+  base_params(sp);
+  sp.dim = 2, sp.degree = 1, sp.ncomp = 1, sp.n_cells = 32, sp.lo = 0, sp.hi = 1;
+  sp.center[0] = sp.center[1] = 0.4, sp.radius = 0.2, sp.immersed_refine = 3, sp.coupling_nq = 3;
+  sp.embedded_value[0] = 1.0;
+  char err[256];
+  void *h = alfd_synth_generate(&sp, err, 256);
+  if (!h) return std::fprintf(stderr, "generator: %s\n", err), 2;
+  mock::SparseMatrix stiffness_matrix = load(h, "A"), coupling_matrix = load(h, "Ct"), mass_matrix = load(h, "M"),
+                     embedded_stiffness_matrix = load(h, "K");
+  const size_t n_u = stiffness_matrix.m(), n_l = mass_matrix.m();
+  // rho_bound = ||A_Gamma||_inf / min_i M_ii (immersed_laplace.cc:609-614)
+  double linfty = 0, min_m = 1e300;
+  for (size_t i = 0; i < n_l; ++i) {
+    double rs = 0;
+    for (auto it = embedded_stiffness_matrix.begin(i); it != embedded_stiffness_matrix.end(i); ++it)
+      rs += std::fabs(it->value());
+    linfty = std::max(linfty, rs);
+    min_m = std::min(min_m, mass_matrix.diag_element(i));
+  }
+  System gpu(0);
+  gpu.set_matrix(ALFD_A, stiffness_matrix);
+  gpu.set_matrix(ALFD_CT, coupling_matrix);
+  gpu.set_matrix(ALFD_M, mass_matrix);
+  gpu.set_matrix(ALFD_KIMM, embedded_stiffness_matrix);
+  alfd_config cfg;
+  alfd_default_config(&cfg, ALFD_RATIONAL);        // outer_solver = MinRes (immersed_laplace.cc:629)
+  cfg.rho_bound = linfty / min_m;
+  cfg.inner = {ALFD_CTRL_REDUCTION, 5000, 1e-13, 1e-12};   // K_inv: UMFPACK in the reference (:617-620)
+  cfg.outer = {ALFD_CTRL_REDUCTION, 1000, 1e-10, 1e-12};
+  gpu.configure(cfg);
+  gpu.setup();
+  mock::BlockVector solution_block({n_u, n_l}), system_rhs_block({n_u, n_l});
+  int64_t n;
+  const double *g;
+  alfd_synth_vector(h, "g", &n, &g);
+  for (size_t i = 0; i < n_l; ++i) system_rhs_block.block(1)[i] = g[i];
+  auto AA = gpu.system_operator();
+  RationalPreconditioner rational_prec(gpu);        // immersed_laplace.cc:625-627
+  SolverMinRes<mock::BlockVector> solver_minres(gpu);
+  solver_minres.solve(AA, solution_block, system_rhs_block, rational_prec);   // :631
+  std::printf("outer=%u inner=%lld rational=%lld residual=%.6e\n", solver_minres.last_step(),
+              (long long)solver_minres.last_result().inner_iterations,
+              (long long)solver_minres.last_result().rational_iterations, solver_minres.last_value());
+  bool refused = false;   // a MinRes context must not be driven through the FGMRES class
+  try {
+    SolverFGMRES<mock::BlockVector> wrong(gpu);
+  } catch (const Error &) {
+    refused = true;
+  }
+  std::printf("fgmres_on_minres_context_refused=%d\n", (int)refused);
+  alfd_synth_free(h);
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  using namespace alfd::dealii_adapter;
+  if (argc > 1 && (std::string(argv[1]) == "elliptic" || std::string(argv[1]) == "rational")) {
+    try {
+      return std::string(argv[1]) == "elliptic" ? run_elliptic() : run_rational();
+    } catch (const NoConvergence &e) {
+      std::fprintf(stderr, "NoConvergence at step %u: %s\n", e.last_step, e.what());
+      return 1;
+    } catch (const Error &e) {
+      std::fprintf(stderr, "alfd error %d: %s\n", e.status, e.what());
+      return e.status == ALFD_E_HIP ? 3 : 1;
+    }
+  }
+  alfd_synth_params sp;
+  base_params(sp);
+  sp.dim = 2, sp.degree = 1, sp.ncomp = 1, sp.n_cells = 64, sp.lo = 0, sp.hi = 1;
   sp.center[0] = sp.center[1] = 0.4, sp.radius = 0.2, sp.immersed_refine = 4, sp.coupling_nq = 3;
   sp.embedded_value[0] = 1.0;
-  sp.u_node0 = sp.u_node1 = sp.p_node0 = sp.p_node1 = sp.l0 = sp.l1 = -1;
   char err[256];
   void *h = alfd_synth_generate(&sp, err, 256);
   if (!h) return std::fprintf(stderr, "generator: %s\n", err), 2;

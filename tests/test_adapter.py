@@ -34,6 +34,20 @@ def test_adapter_solve_matches_golden(demo):
     assert f"outer={gold['outer_iterations']} inner={gold['inner_iterations']} " in first, p.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,case", [("elliptic", "elliptic_modified"), ("rational", "rational_minres")])
+def test_adapter_elliptic_and_rational_call_sites_match_golden(demo, mode, case):
+    """elliptic_interface.cc:900-906 (BlockTriangularALPreconditionerModified + SolverFGMRES) and
+    immersed_laplace.cc:625-631 (RationalPreconditioner + SolverMinRes) through the C++ adapter."""
+    p = subprocess.run([demo, mode], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    gold = json.load(open(os.path.join(HERE, "golden", "solves.json")))[case]
+    first = p.stdout.splitlines()[0]
+    assert f"outer={gold['outer_iterations']} inner={gold['inner_iterations']} " in first, p.stdout
+    if mode == "rational":
+        assert f"rational={gold['rational_iterations']} " in first and "refused=1" in p.stdout
+
+
 def test_cpp_exporter_round_trips_through_the_wire_format(demo, tmp_path):
     """include/alfd/dealii_export.hpp (driven through the mock SparseMatrix with
     diagonal-first rows) -> .alfd file -> opfile.load(): identical to the Python-side

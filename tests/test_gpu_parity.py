@@ -407,3 +407,68 @@ def test_properties_at_bench_scale(built):
     assert np.array_equal(ctx.history(), h1) and all(np.array_equal(p_, q_) for p_, q_ in zip(x, x2))
     assert np.all(np.diff(h1) <= 0)
     ctx.close()
+
+
+def _full_size_properties(pb, cfg, rhs, aggs, outer_band, symmetric, augment):
+    """Size-independent checks on a full-size BASELINE config (no oracle at this size): linearity of the
+    system operator, its symmetry where it is symmetric, the A-SpMV against SciPy, the true residual of
+    the returned solution against the stop rule, bitwise repeatability, the outer-iteration band."""
+    ctx = solver.context_from_problem(pb, cfg, aggregates=aggs)
+    try:
+        rng = np.random.default_rng(1)
+        xs = [[rng.uniform(-1, 1, n_) for n_ in pb.block_sizes] for _ in range(2)]
+        a, b = 0.75, -1.25
+        y0, y1 = ctx.system_apply(xs[0]), ctx.system_apply(xs[1])
+        ysum = ctx.system_apply([a * u + b * v for u, v in zip(*xs)])
+        for s_, u, v in zip(ysum, y0, y1):
+            assert np.allclose(s_, a * u + b * v, rtol=0, atol=1e-11 * max(np.abs(u).max(), np.abs(v).max()))
+        if symmetric:
+            lhs = sum(float(np.dot(u, v)) for u, v in zip(y0, xs[1]))
+            rhs_ = sum(float(np.dot(u, v)) for u, v in zip(xs[0], y1))
+            assert abs(lhs - rhs_) <= 1e-10 * max(abs(lhs), 1.0)
+        u = xs[0][0]
+        ax, _ = ctx.spmv(_abi.A, u, np.zeros(pb.block_sizes[0]))
+        ref = pb.mats["A"].to_scipy() @ u
+        assert np.allclose(ax, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+        if augment:
+            rhs = ctx.augment_rhs(rhs)
+        x, res = ctx.solve(rhs)
+        h1 = ctx.history()
+        axx = ctx.system_apply(x)
+        r = np.sqrt(sum(float(np.dot(p_ - q_, p_ - q_)) for p_, q_ in zip(rhs, axx)))
+        assert res.status == 0 and r <= 10 * max(cfg.outer.tol, cfg.outer.reduce * res.initial_residual)
+        assert outer_band[0] <= res.outer_iterations <= outer_band[1], res.outer_iterations
+        x2, res2 = ctx.solve(rhs)
+        assert np.array_equal(ctx.history(), h1) and all(np.array_equal(p_, q_) for p_, q_ in zip(x, x2))
+        return res
+    finally:
+        ctx.close()
+
+
+def test_properties_cfg2_full_size(built):
+    """BASELINE cfg 2 at full size: immersed_laplace 3-D, Q1 on 128^3 cells (2.15 M DoF), cubed sphere with
+    6146 multiplier DoFs, Circle_parameters-style controls."""
+    pb = problems.laplace3d_sphere(128, 5)
+    assert pb.block_sizes == [2146689, 6146]
+    cfg = _abi.default_config(_abi.AL2)
+    cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
+    cfg.inner.max_steps = 5000
+    res = _full_size_properties(pb, cfg, [pb.vecs["f"], pb.vecs["g"]], None, (4, 12), True, True)
+    assert res.inner_iterations > 0
+
+
+@pytest.mark.parametrize("beta2", [10.0, 1e3])
+def test_properties_cfg3_full_size(built, beta2):
+    """BASELINE cfg 3 at full size: elliptic_interface 2-D, modified AL, background Q1 on 1024^2, immersed Q1 on
+    256^2 (1.05 M + 2 x 66 k DoF), beta_2 = 10 (parameters_modified.prm:5) and 1e3 (BASELINE.json)."""
+    pb = problems.elliptic_interface2d(1024, 256, beta2=beta2)
+    assert pb.block_sizes == [1050625, 66049, 66049]
+    cfg = _abi.default_config(_abi.AL_ELL_MODIFIED)
+    cfg.gamma, cfg.gamma2 = 10.0, 1e-2
+    cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 100000, 1e-2, 1e-20)
+    cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-10)
+    cfg.inner_prec = _abi.PREC_MULTILEVEL
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+    aggs = problems.geometric_aggregates(pb, a=2, min_coarse=600)
+    rhs = [pb.vecs["f"], pb.vecs["f2"], np.zeros(pb.block_sizes[2])]
+    _full_size_properties(pb, cfg, rhs, aggs, (15, 60), False, False)
