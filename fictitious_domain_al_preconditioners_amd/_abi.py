@@ -23,6 +23,8 @@ PREC_IDENTITY, PREC_JACOBI, PREC_CHEBYSHEV, PREC_MULTILEVEL = range(4)
 ORTH_MGS, ORTH_CGS, ORTH_CGS2 = range(3)
 # enum alfd_outer_solver
 OUTER_FGMRES, OUTER_MINRES = range(2)
+# enum alfd_fgmres_flavour
+FGMRES_DEALII_96, FGMRES_DEALII_95 = range(2)
 # enum alfd_w_inverse
 W_DIAGONAL, W_MASS_INV_SQUARED, W_MASS_INV = range(3)
 # enum alfd_inner_failure_policy
@@ -55,6 +57,7 @@ class Config(C.Structure):
         ("ml_smooth_ratio", C.c_double), ("ml_coarse_ratio", C.c_double),
         ("aug_assembled", C.c_int32), ("w_inverse", C.c_int32),
         ("mass", Control),
+        ("fgmres_flavour", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

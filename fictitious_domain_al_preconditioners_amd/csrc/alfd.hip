@@ -1236,6 +1236,118 @@ static int fgmres(alfd_ctx *ctx, alfd_result *out) {
   return ALFD_OK;
 }
 
+// Least squares min || beta e1 - H(0:n, 0:n-1) y || of the (n+1) x n leading Hessenberg block by
+// Givens rotations (deal.II <= 9.5 uses Householder::least_squares: the same minimiser).  H is
+// stored row-major with leading dimension m.  Returns the residual norm, y[0..n).
+static double hessenberg_lsq(const std::vector<double> &H, int m, int n, double beta, std::vector<double> &y) {
+  std::vector<double> R((size_t)(n + 1) * n), g(n + 1, 0.0);
+  for (int i = 0; i <= n; ++i)
+    for (int j = 0; j < n; ++j) R[(size_t)i * n + j] = H[(size_t)i * m + j];
+  g[0] = beta;
+  for (int j = 0; j < n; ++j) {
+    const double a = R[(size_t)j * n + j], b = R[(size_t)(j + 1) * n + j];
+    const double denom = std::sqrt(a * a + b * b);
+    const double c = a / denom, sn = b / denom;
+    for (int l = j; l < n; ++l) {
+      const double t = c * R[(size_t)j * n + l] + sn * R[(size_t)(j + 1) * n + l];
+      R[(size_t)(j + 1) * n + l] = -sn * R[(size_t)j * n + l] + c * R[(size_t)(j + 1) * n + l];
+      R[(size_t)j * n + l] = t;
+    }
+    const double t = c * g[j];
+    g[j + 1] = -sn * g[j];
+    g[j] = t;
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double sum = g[i];
+    for (int l = i + 1; l < n; ++l) sum -= R[(size_t)i * n + l] * y[l];
+    y[i] = sum / R[(size_t)i * n + i];
+  }
+  return std::fabs(g[n]);
+}
+
+// SolverFGMRES of deal.II <= 9.5 [EXT] (alfd_fgmres_flavour): modified Gram-Schmidt, delayed
+// least-squares check, no counter increment at j = 0 of a cycle.
+static int fgmres_dealii95(alfd_ctx *ctx, alfd_result *out) {
+  const alfd_config &c = ctx->cfg;
+  const int m = c.restart;
+  const int64_t N = ctx->ntot();
+  double *x = ctx->xb, *b = ctx->bb;
+  std::vector<double> H((size_t)(m + 1) * m, 0.0), y(m, 0.0);
+  Control sc{c.outer};
+  int k = 0;
+  State st = ITERATE;
+  double res = 0;
+  ctx->history.clear();
+  auto Vj = [&](int j) { return ctx->V + (int64_t)j * N; };
+  auto Zj = [&](int j) { return ctx->Z + (int64_t)j * N; };
+  double *aux = Vj(m);
+  auto dotv = [&](const double *p, const double *q, double *r) -> int {
+    RC(dot_async(ctx, N, p, q, S_TMP));
+    RC(read_scalars(ctx, S_TMP, 1));
+    *r = ctx->sc_host[S_TMP];
+    return ALFD_OK;
+  };
+  do {
+    RC(system_apply(ctx, x, aux));
+    VEC_LAUNCH(sub_from_kernel, N, 24, b, aux);                  // aux = b - AA x
+    double bb2 = 0;
+    RC(dotv(aux, aux, &bb2));
+    const double beta = std::sqrt(bb2);
+    res = beta;
+    st = sc.check(k, res);
+    if (k == 0) ctx->history.push_back(res);
+    if (c.log_level >= 2 && ctx->rank == 0) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
+    if (st != ITERATE) break;
+    std::fill(H.begin(), H.end(), 0.0);
+    double a = beta;
+    int ny = 0;
+    for (int j = 0; j < m; ++j) {
+      if (a != 0.0) VEC_LAUNCH(scale_copy_kernel, N, 16, 1.0 / a, aux, Vj(j));   // v_j = aux / a
+      else HIPC(hipMemsetAsync(Vj(j), 0, N * sizeof(double), ctx->stream));
+      RC(precond_apply(ctx, Vj(j), Zj(j)));
+      RC(system_apply(ctx, Zj(j), aux));
+      double h = 0;
+      RC(dotv(aux, Vj(0), &h));
+      H[(size_t)0 * m + j] = h;
+      for (int i = 0; i < j; ++i) {                              // H(i+1,j) = (aux -= H(i,j) v_i) . v_{i+1}
+        VEC_LAUNCH(axpy_kernel, N, 24, (const double *)nullptr, 0, -H[(size_t)i * m + j], Vj(i), aux);
+        RC(dotv(aux, Vj(i + 1), &h));
+        H[(size_t)(i + 1) * m + j] = h;
+      }
+      VEC_LAUNCH(axpy_kernel, N, 24, (const double *)nullptr, 0, -H[(size_t)j * m + j], Vj(j), aux);
+      RC(dotv(aux, aux, &h));
+      H[(size_t)(j + 1) * m + j] = a = std::sqrt(h);
+      if (j > 0) {
+        res = hessenberg_lsq(H, m, j, beta, y);
+        ny = j;
+        ++k;
+        st = sc.check(k, res);
+        ctx->history.push_back(res);
+        if (c.log_level >= 2 && ctx->rank == 0) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
+        if (st != ITERATE) break;
+      }
+    }
+    for (int i = 0; i < ny; ++i) ctx->sc_host[S_H + i] = y[i];
+    if (ny > 0) {
+      HIPC(hipMemcpyAsync(ctx->sc + S_H, ctx->sc_host + S_H, ny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      VEC_LAUNCH(multi_axpy_kernel, N, 8.0 * (ny + 2), ctx->Z, N, ny, ctx->sc, (int)S_H, x);
+    }
+    HIPC(hipStreamSynchronize(ctx->stream));
+  } while (st == ITERATE);
+  out->outer_iterations = k;
+  out->initial_residual = sc.initial;
+  out->last_residual = res;
+  if (c.log_level >= 1 && ctx->rank == 0)
+    std::printf(st == SUCCESS ? "DEAL:FGMRES::Convergence step %d value %.17g\n"
+                              : "DEAL:FGMRES::Failure step %d value %.17g\n",
+                k, res);
+  if (st != SUCCESS) {
+    ctx->err = "FGMRES did not converge (SolverControl::NoConvergence)";
+    return std::isnan(res) ? ALFD_E_BREAKDOWN : ALFD_E_NO_CONVERGENCE_OUTER;
+  }
+  return ALFD_OK;
+}
+
 // deal.II SolverMinRes [EXT] on device vectors (immersed_laplace.cc:629-631,
 // stokes...:1057-1064).  Vectors: u0,u1,u2 | m0,m1,m2 | v live in the Krylov arenas.
 static int minres(alfd_ctx *ctx, alfd_result *out) {
@@ -2292,6 +2404,104 @@ static int gather_vec(alfd_ctx *ctx, const double *d_local, int64_t n_local, dou
   return ALFD_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Algebraic aggregation (alfd_build_aggregates): the counterpart of ML's uncoupled aggregation
+// (utilities.h:304-317: aggregation_threshold, constant modes per component) for operators that
+// come without grid information -- a matrix replayed from an .alfd file, a locally refined mesh
+// with hanging-node rows.  Unknowns are taken node-major with `bs` components per node.  Per
+// level: node graph with w_IJ = max |a_ij| over the bs x bs block, strong if
+// w_IJ >= theta sqrt(d_I d_J) (d = max |a_ii| of the node); rows that hold only their diagonal
+// (Dirichlet / constrained rows) stay out (-1).  Greedy passes in natural order (deterministic):
+// (1) a free node whose strong neighbours are all free founds an aggregate with its strongest
+// free neighbours (at most max_size nodes); (2) leftovers join the founded aggregate they are most
+// strongly tied to; (3) what is still free founds aggregates of its own.  The next level's graph
+// is that of the Galerkin product with the piecewise-constant prolongator.
+static void aggregate_level(const HostCsr &A, int bs, double theta, int max_size, std::vector<int32_t> &agg,
+                            int64_t &n_coarse) {
+  const int64_t n = A.nrows, nn = n / bs;
+  std::vector<double> d(nn, 0.0);
+  std::vector<char> fixed(nn, 1);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t I = i / bs;
+    for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+      if (A.col[k] == i) d[I] = std::max(d[I], std::fabs(A.val[k]));
+      else if (A.val[k] != 0.0) fixed[I] = 0;
+    }
+  }
+  // node graph (strong edges only), CSR with weights
+  std::vector<int64_t> gp(nn + 1, 0);
+  std::vector<int32_t> gc;
+  std::vector<double> gw;
+  {
+    std::vector<double> w(nn, 0.0);
+    std::vector<int32_t> touched;
+    for (int64_t I = 0; I < nn; ++I) {
+      touched.clear();
+      if (!fixed[I])
+        for (int64_t i = I * bs; i < (I + 1) * bs; ++i)
+          for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+            const int64_t J = A.col[k] / bs;
+            if (J == I || J >= nn || fixed[J]) continue;
+            const double v = std::fabs(A.val[k]);
+            if (v == 0.0) continue;
+            if (w[J] == 0.0) touched.push_back((int32_t)J);
+            w[J] = std::max(w[J], v);
+          }
+      std::sort(touched.begin(), touched.end());
+      for (int32_t J : touched) {
+        if (w[J] >= theta * std::sqrt(d[I] * d[J])) {
+          gc.push_back(J);
+          gw.push_back(w[J]);
+        }
+        w[J] = 0.0;
+      }
+      gp[I + 1] = (int64_t)gc.size();
+    }
+  }
+  std::vector<int32_t> na(nn, -1);  // node -> aggregate
+  int32_t nagg = 0;
+  std::vector<std::pair<double, int32_t>> cand;
+  // pass 1
+  for (int64_t I = 0; I < nn; ++I) {
+    if (fixed[I] || na[I] >= 0) continue;
+    bool all_free = true;
+    for (int64_t k = gp[I]; k < gp[I + 1] && all_free; ++k) all_free = na[gc[k]] < 0;
+    if (!all_free) continue;
+    cand.clear();
+    for (int64_t k = gp[I]; k < gp[I + 1]; ++k) cand.emplace_back(-gw[k], gc[k]);
+    std::sort(cand.begin(), cand.end());   // strongest first, ties by node id
+    na[I] = nagg;
+    for (size_t q = 0; q < cand.size() && (int)q + 1 < max_size; ++q) na[cand[q].second] = nagg;
+    ++nagg;
+  }
+  // pass 2: join the most strongly tied aggregate of pass 1
+  const int32_t nagg1 = nagg;
+  std::vector<int32_t> join(nn, -1);
+  for (int64_t I = 0; I < nn; ++I) {
+    if (fixed[I] || na[I] >= 0) continue;
+    double best = 0.0;
+    for (int64_t k = gp[I]; k < gp[I + 1]; ++k) {
+      const int32_t a = na[gc[k]];
+      if (a >= 0 && a < nagg1 && gw[k] > best) best = gw[k], join[I] = a;
+    }
+  }
+  for (int64_t I = 0; I < nn; ++I)
+    if (join[I] >= 0) na[I] = join[I];
+  // pass 3: the rest founds its own aggregates (with whatever free strong neighbours are left)
+  for (int64_t I = 0; I < nn; ++I) {
+    if (fixed[I] || na[I] >= 0) continue;
+    na[I] = nagg;
+    int taken = 1;
+    for (int64_t k = gp[I]; k < gp[I + 1] && taken < max_size; ++k)
+      if (na[gc[k]] < 0) na[gc[k]] = nagg, ++taken;
+    ++nagg;
+  }
+  agg.assign(n, -1);
+  for (int64_t i = 0; i < nn * bs; ++i)
+    if (na[i / bs] >= 0) agg[i] = (int32_t)(na[i / bs] * bs + i % bs);
+  n_coarse = (int64_t)nagg * bs;
+}
+
 static int ml_setup(alfd_ctx *ctx) {
   const alfd_config &c = ctx->cfg;
   if (c.ml_smooth_degree < 1 || c.ml_coarse_degree < 1 || !(c.ml_smooth_ratio > 1.0) || !(c.ml_coarse_ratio > 1.0))
@@ -2484,6 +2694,10 @@ static int setup(alfd_ctx *ctx) {
   if (c.outer_solver == ALFD_OUTER_MINRES && c.restart < 4)
     return ctx->err = "MinRes needs restart >= 4 (vector arena)", ALFD_E_INVALID;
   if (c.restart < 1 || c.restart > kMaxBasis - 1) return ctx->err = "restart out of range", ALFD_E_INVALID;
+  if (c.fgmres_flavour != ALFD_FGMRES_DEALII_96 && c.fgmres_flavour != ALFD_FGMRES_DEALII_95)
+    return ctx->err = "unknown alfd_config::fgmres_flavour", ALFD_E_INVALID;
+  if (c.fgmres_flavour == ALFD_FGMRES_DEALII_95 && c.restart < 2)
+    return ctx->err = "the deal.II <= 9.5 FGMRES loop needs restart >= 2", ALFD_E_INVALID;
   const bool ell = is_elliptic(c.variant);
   if (!c.grad_div_in_A && (c.variant == ALFD_AL_STOKES || c.variant == ALFD_AL_STOKES_DIAG))
     return ctx->err = "grad_div_in_A = 0 (nested Bt Mp^-1 B in Aug) not implemented", ALFD_E_UNSUPPORTED;
@@ -3003,6 +3217,65 @@ int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t
   return ALFD_OK;
 }
 
+int alfd_build_aggregates(alfd_ctx_t ctx, int32_t block_size, double threshold, int32_t max_aggregate_nodes,
+                          int64_t min_coarse, int32_t max_levels, int32_t *levels_out) {
+  CHECK_CTX();
+  if (ctx->nranks > 1) return ctx->err = "alfd_build_aggregates is single-rank", ALFD_E_UNSUPPORTED;
+  if (!ctx->mat[ALFD_A].present) return ctx->err = "upload slot A first", ALFD_E_NOT_SETUP;
+  if (block_size < 1 || !(threshold >= 0.0) || max_aggregate_nodes < 2 || min_coarse < 1) return ALFD_E_INVALID;
+  if (ctx->mat[ALFD_A].nrows % block_size) return ctx->err = "rows of A are not a multiple of block_size", ALFD_E_INVALID;
+  if (max_levels < 1 || max_levels > ALFD_MAX_LEVELS - 1) max_levels = ALFD_MAX_LEVELS - 1;
+  HostCsr A, An;
+  RC(download_csr(ctx, ctx->mat[ALFD_A], A));
+  for (int l = 0; l < ALFD_MAX_LEVELS; ++l) ctx->ml_agg[l].clear(), ctx->ml_wgt[l].clear();
+  int nlev = 0;
+  while (nlev < max_levels) {
+    std::vector<int32_t> agg;
+    int64_t nc = 0;
+    aggregate_level(A, block_size, threshold, max_aggregate_nodes, agg, nc);
+    if (nc < 1 || nc >= A.nrows) break;     // nothing left to coarsen
+    ctx->ml_agg[nlev] = agg;
+    ctx->ml_ncoarse[nlev] = nc;
+    ++nlev;
+    if (nc <= min_coarse) break;
+    galerkin(A, agg.data(), nullptr, nc, agg.data(), nullptr, nc, An);
+    std::swap(A, An);
+  }
+  if (nlev == 0) return ctx->err = "algebraic aggregation found nothing to coarsen", ALFD_E_INVALID;
+  if (levels_out) *levels_out = nlev;
+  ctx->is_setup = false;
+  return ALFD_OK;
+}
+
+int alfd_host_aggregate_level(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val,
+                               int32_t block_size, double threshold, int32_t max_aggregate_nodes, int32_t *agg,
+                               int64_t *n_coarse) {
+  if (nrows < 1 || !rp || !col || !val || !agg || !n_coarse || block_size < 1 || nrows % block_size ||
+      max_aggregate_nodes < 2 || !(threshold >= 0.0))
+    return ALFD_E_INVALID;
+  HostCsr A;
+  A.nrows = A.ncols = nrows;
+  A.rp.assign(rp, rp + nrows + 1);
+  A.col.assign(col, col + rp[nrows]);
+  A.val.assign(val, val + rp[nrows]);
+  std::vector<int32_t> a;
+  aggregate_level(A, block_size, threshold, max_aggregate_nodes, a, *n_coarse);
+  std::copy(a.begin(), a.end(), agg);
+  return ALFD_OK;
+}
+
+int alfd_get_aggregates(alfd_ctx_t ctx, int level, int32_t *agg, int64_t capacity, int64_t *n_fine, int64_t *n_coarse) {
+  if (!ctx || level < 0 || level >= ALFD_MAX_LEVELS || ctx->ml_agg[level].empty()) return ALFD_E_INVALID;
+  const std::vector<int32_t> &a = ctx->ml_agg[level];
+  if (n_fine) *n_fine = (int64_t)a.size();
+  if (n_coarse) *n_coarse = ctx->ml_ncoarse[level];
+  if (agg) {
+    if (capacity < (int64_t)a.size()) return ALFD_E_INVALID;
+    std::copy(a.begin(), a.end(), agg);
+  }
+  return ALFD_OK;
+}
+
 int alfd_set_aggregate_partition(alfd_ctx_t ctx, int level, const int64_t *coarse_offsets) {
   CHECK_CTX();
   if (level < 0 || level >= ALFD_MAX_LEVELS || !coarse_offsets) return ALFD_E_INVALID;
@@ -3088,7 +3361,9 @@ int alfd_solve_resident(alfd_ctx_t ctx, alfd_result *res) {
   HIPC(hipMemcpyAsync(ctx->xb, ctx->io, ctx->ntot() * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   HIPC(hipStreamSynchronize(ctx->stream));
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = ctx->cfg.outer_solver == ALFD_OUTER_MINRES ? minres(ctx, res) : fgmres(ctx, res);
+  const int rc = ctx->cfg.outer_solver == ALFD_OUTER_MINRES               ? minres(ctx, res)
+                 : ctx->cfg.fgmres_flavour == ALFD_FGMRES_DEALII_95 ? fgmres_dealii95(ctx, res)
+                                                                    : fgmres(ctx, res);
   hipStreamSynchronize(ctx->stream);
   res->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   flush_timers(ctx);

@@ -524,7 +524,8 @@ struct Immersed {
 Immersed make_circle(const Params &P) {
   Immersed im;
   im.cell_nodes = 2;
-  const int n = 4 << P.immersed_refine;
+  // 4 * 2^refine segments (GridGenerator::hyper_sphere<1,2> refined), or exactly imm_cells segments
+  const int n = (P.immersed_kind == 0 && P.imm_cells > 0) ? P.imm_cells : 4 << P.immersed_refine;
   for (int i = 0; i < n; ++i) {
     const double th = 2.0 * M_PI * i / n;
     im.xyz.push_back(P.center[0] + P.radius * std::cos(th));

@@ -198,7 +198,7 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
              gamma_grad_div=0.0, beta=1.0, center=(0.5, 0.5, 0.5), radius=0.2, immersed_refine=3,
              coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0),
              row_ranges=None, immersed_box=None, beta2=0.0, surface_mass=False,
-             elasticity=None, immersed_box3d=None) -> SyntheticProblem:
+             elasticity=None, immersed_box3d=None, immersed_segments=0) -> SyntheticProblem:
     """immersed_box = (lo, hi, cells): the immersed domain is the 2-D box [lo,hi]^2
     with cells^2 Q1 cells (volume coupling, elliptic_interface); beta2 scales "A2".
     elasticity = (lambda, mu, lambda_jump, mu_jump): vector-Q1 linear elasticity on the background
@@ -224,6 +224,8 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     if immersed_box is not None:
         p.immersed_kind, p.imm_lo, p.imm_hi, p.imm_cells = 1, float(immersed_box[0]), float(immersed_box[1]), int(immersed_box[2])
         p.beta2 = beta2
+    if immersed_segments:       # 2-D circle with exactly this many P1 segments (closed curve: as many nodes)
+        p.imm_cells = int(immersed_segments)
     if immersed_box3d is not None:
         p.immersed_kind = 2
         for i in range(3):
@@ -262,12 +264,14 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
 
 # ---------------------------------------------------------------------------
 # The BASELINE.json configs as concrete synthetic instances.
-def laplace2d_circle(n_cells=64, immersed_refine=5, coupling_nq=3, surface_mass=False) -> SyntheticProblem:
+def laplace2d_circle(n_cells=64, immersed_refine=5, coupling_nq=3, surface_mass=False,
+                     immersed_segments=0) -> SyntheticProblem:
     """cfg 1: immersed_laplace 2-D, parameters/circle/Circle_parameters_f0_g1.prm
     (f = 0, g = 1, R = 0.2, centre (0.4, 0.4)), Q1 background on [0,1]^2."""
     return generate(dim=2, degree=1, ncomp=1, n_cells=n_cells, center=(0.4, 0.4, 0.0), radius=0.2,
                     immersed_refine=immersed_refine, coupling_nq=coupling_nq,
-                    body_force=(0.0,), embedded_value=(1.0,), surface_mass=surface_mass)
+                    body_force=(0.0,), embedded_value=(1.0,), surface_mass=surface_mass,
+                    immersed_segments=immersed_segments)
 
 
 def operator_form(pb: SyntheticProblem, gamma: float = 10.0):

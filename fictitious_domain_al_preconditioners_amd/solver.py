@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "alfd_enable_timing", "alfd_get_timing", "alfd_host_halo_plan", "alfd_local_group_create",
     "alfd_local_group_destroy", "alfd_comm_init_local", "alfd_set_aggregates",
     "alfd_set_aggregate_partition", "alfd_get_matrix_info", "alfd_bench_spmv_format",
-    "alfd_host_window_plan", "alfd_set_tunable",
+    "alfd_host_window_plan", "alfd_set_tunable", "alfd_build_aggregates", "alfd_get_aggregates",
+    "alfd_host_aggregate_level",
 ]
 
 
@@ -95,6 +96,9 @@ def load_library():
         "alfd_bench_spmv_format": (C.c_int, [vp, C.c_int, i32, C.c_int, C.POINTER(dbl), C.POINTER(dbl)]),
         "alfd_host_window_plan": (C.c_int, [i64, vp, vp, vp, i32, i32, C.POINTER(_abi.WindowPlanInfo)]),
         "alfd_set_tunable": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "alfd_build_aggregates": (C.c_int, [vp, i32, dbl, i32, i64, i32, C.POINTER(i32)]),
+        "alfd_get_aggregates": (C.c_int, [vp, C.c_int, vp, i64, C.POINTER(i64), C.POINTER(i64)]),
+        "alfd_host_aggregate_level": (C.c_int, [i64, vp, vp, vp, i32, dbl, i32, vp, C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -174,6 +178,21 @@ class Context:
         w = None if weight is None else np.ascontiguousarray(weight, np.float64)
         self._ck(self._lib.alfd_set_aggregates(self._h, level, agg.size, agg.ctypes.data,
                                                None if w is None else w.ctypes.data, int(n_coarse)))
+
+    def build_aggregates(self, block_size=1, threshold=0.02, max_aggregate_nodes=8, min_coarse=600, max_levels=7):
+        """Algebraic aggregation from the uploaded A alone (alfd_build_aggregates); returns
+        [(agg, n_coarse), ...] -- the list Context.set_aggregates / the oracle take."""
+        nlev = C.c_int32(0)
+        self._ck(self._lib.alfd_build_aggregates(self._h, block_size, threshold, max_aggregate_nodes, min_coarse,
+                                                 max_levels, C.byref(nlev)))
+        out = []
+        for level in range(nlev.value):
+            nf, nc = C.c_int64(0), C.c_int64(0)
+            self._ck(self._lib.alfd_get_aggregates(self._h, level, None, 0, C.byref(nf), C.byref(nc)))
+            agg = np.empty(nf.value, np.int32)
+            self._ck(self._lib.alfd_get_aggregates(self._h, level, agg.ctypes.data, agg.size, C.byref(nf), C.byref(nc)))
+            out.append((agg, int(nc.value)))
+        return out
 
     def set_aggregate_partition(self, level, coarse_offsets):
         o = np.ascontiguousarray(coarse_offsets, np.int64)
@@ -331,6 +350,21 @@ def host_halo_plan(col, col_offsets, rank):
     if rc != _abi.OK:
         raise AlfdError(rc, "alfd_host_halo_plan failed")
     return col_local, halo[:n_halo.value].copy(), recv_off
+
+
+def host_aggregate_level(m, block_size=1, threshold=0.02, max_aggregate_nodes=8):
+    """Host-only: one level of the library's algebraic aggregation on a problems.Csr; (agg, n_coarse)."""
+    lib = load_library()
+    rp = np.ascontiguousarray(m.row_ptr, np.int64)
+    col = np.ascontiguousarray(m.col, np.int32)
+    val = np.ascontiguousarray(m.val, np.float64)
+    agg = np.empty(m.nrows, np.int32)
+    nc = C.c_int64(0)
+    rc = lib.alfd_host_aggregate_level(m.nrows, rp.ctypes.data, col.ctypes.data, val.ctypes.data, block_size,
+                                       threshold, max_aggregate_nodes, agg.ctypes.data, C.byref(nc))
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_aggregate_level failed")
+    return agg, int(nc.value)
 
 
 def host_window_plan(m, lanes=64, value_index=True):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 7
+#define ALFD_ABI_VERSION 9
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -126,6 +126,17 @@ enum alfd_inner_prec {
  * Gram-Schmidt; >= 9.6 classical Gram-Schmidt variants. */
 enum alfd_orthogonalization { ALFD_ORTH_MGS = 0, ALFD_ORTH_CGS = 1, ALFD_ORTH_CGS2 = 2 };
 
+/* Which deal.II release's SolverFGMRES loop is followed [EXT] (CMakeLists.txt:6 asks for 9.6.0, README.md:45
+ * for 9.7): they differ in what last_step() counts.
+ *   DEALII_96  >= 9.6: Arnoldi process with Givens rotations; the residual is checked and the counter
+ *              incremented after EVERY Arnoldi step; the true residual of a restart is re-checked with the
+ *              same counter.  Orthogonalisation: alfd_config::orthogonalization.
+ *   DEALII_95  <= 9.5: modified Gram-Schmidt by add_and_dot; within a cycle the projected least-squares
+ *              problem is solved with the FIRST j columns after the (j+1)-th Arnoldi vector was built
+ *              (no check, no increment at j = 0), so a cycle of m preconditioner applications counts
+ *              m - 1 steps and uses m - 1 of its m search directions.  Needs restart >= 2. */
+enum alfd_fgmres_flavour { ALFD_FGMRES_DEALII_96 = 0, ALFD_FGMRES_DEALII_95 = 1 };
+
 /* Outer Krylov method: SolverFGMRES (stokes...:1067) or SolverMinRes
  * (stokes...:1057-1064 with the diagonal SPD preconditioner; immersed_laplace.cc:629-631
  * with the rational preconditioner).  MinRes needs a symmetric system and an SPD
@@ -179,6 +190,8 @@ typedef struct alfd_config {
   int32_t aug_assembled;
   int32_t w_inverse;          /* enum alfd_w_inverse */
   alfd_control mass;          /* CG on M for the exact W^-1: ReductionControl(1000, 1e-30, 1e-14) */
+  int32_t fgmres_flavour;     /* enum alfd_fgmres_flavour */
+  int32_t reserved0;
 } alfd_config;
 
 typedef struct alfd_result {
@@ -265,6 +278,24 @@ int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t
  * unknowns of each level are numbered rank-major, coarse_offsets[nranks+1] gives the rank
  * ranges.  An aggregate must not span two ranks. */
 int alfd_set_aggregate_partition(alfd_ctx_t ctx, int level, const int64_t *coarse_offsets);
+/* Algebraic aggregation for callers without grid information (a matrix replayed from an .alfd
+ * file, a locally refined mesh with hanging-node rows): builds the aggregates of every level from
+ * the uploaded slot A alone and stores them as alfd_set_aggregates would -- the counterpart of
+ * ML's uncoupled aggregation (utilities.h:304-317: aggregation_threshold 0.02, one constant mode
+ * per component).  Unknowns are node-major with block_size components per node; a node pair is
+ * strongly coupled if max |a_ij| >= threshold * sqrt(d_I d_J); rows holding only their diagonal
+ * (Dirichlet / constrained rows) are left out; aggregates hold at most max_aggregate_nodes nodes.
+ * Coarsening stops at <= min_coarse unknowns or max_levels.  Deterministic (natural order).
+ * Single rank.  alfd_get_aggregates returns a level (agg may be NULL to query the sizes), e.g. to
+ * hand the same aggregates to another solver instance. */
+int alfd_build_aggregates(alfd_ctx_t ctx, int32_t block_size, double threshold, int32_t max_aggregate_nodes,
+                          int64_t min_coarse, int32_t max_levels, int32_t *levels_out);
+int alfd_get_aggregates(alfd_ctx_t ctx, int level, int32_t *agg, int64_t capacity, int64_t *n_fine,
+                        int64_t *n_coarse);
+/* Host-only (no device, no context): ONE level of the same aggregation on a CSR matrix; agg[nrows]. */
+int alfd_host_aggregate_level(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                              int32_t block_size, double threshold, int32_t max_aggregate_nodes, int32_t *agg,
+                              int64_t *n_coarse);
 int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg);
 void alfd_default_config(alfd_config *cfg, int variant);
 /* Builds transposes, sparse-row views, diag(Aug), lambda_max, halo plans

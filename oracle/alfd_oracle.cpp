@@ -1133,6 +1133,101 @@ static int fgmres(Problem &P, const double *b, double *x, alfd_result *out,
   return ALFD_OK;
 }
 
+// (n+1) x n Hessenberg least squares by Givens rotations; H row-major with leading dimension m.
+static double hessenberg_lsq(const std::vector<double> &H, int m, int n, double beta, std::vector<double> &y) {
+  std::vector<double> R((size_t)(n + 1) * n), g(n + 1, 0.0);
+  for (int i = 0; i <= n; ++i)
+    for (int j = 0; j < n; ++j) R[(size_t)i * n + j] = H[(size_t)i * m + j];
+  g[0] = beta;
+  for (int j = 0; j < n; ++j) {
+    const double a = R[(size_t)j * n + j], b = R[(size_t)(j + 1) * n + j];
+    const double denom = std::sqrt(a * a + b * b);
+    const double c = a / denom, sn = b / denom;
+    for (int l = j; l < n; ++l) {
+      const double t = c * R[(size_t)j * n + l] + sn * R[(size_t)(j + 1) * n + l];
+      R[(size_t)(j + 1) * n + l] = -sn * R[(size_t)j * n + l] + c * R[(size_t)(j + 1) * n + l];
+      R[(size_t)j * n + l] = t;
+    }
+    const double t = c * g[j];
+    g[j + 1] = -sn * g[j];
+    g[j] = t;
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double sum = g[i];
+    for (int l = i + 1; l < n; ++l) sum -= R[(size_t)i * n + l] * y[l];
+    y[i] = sum / R[(size_t)i * n + i];
+  }
+  return std::fabs(g[n]);
+}
+
+// SolverFGMRES of deal.II <= 9.5 [EXT], written from the published loop (solver_gmres.h of 9.4/9.5):
+//   aux = b - A x; beta = |aux|; check(accumulated, beta)            (no increment)
+//   for j < m: v_j = aux / a; z_j = P v_j; aux = A z_j;
+//              H(0,j) = aux.v_0; H(i+1,j) = aux.add_and_dot(-H(i,j), v_i, v_{i+1});
+//              H(j+1,j) = a = sqrt(aux.add_and_dot(-H(j,j), v_j, aux));
+//              if j > 0: res = least_squares(H(0:j, 0:j-1)); check(++accumulated, res)
+//   x += sum_{i < size(y)} y_i z_i
+static int fgmres_dealii95(Problem &P, const double *b, double *x, alfd_result *out, std::vector<double> &history) {
+  const alfd_config &c = P.cfg;
+  const int m = c.restart;
+  const int64_t N = P.ntot();
+  std::vector<std::vector<double>> V(m, std::vector<double>(N)), Z(m, std::vector<double>(N));
+  std::vector<double> aux(N), H((size_t)(m + 1) * m, 0.0), y(m, 0.0);
+  Control sc{c.outer};
+  int k = 0;
+  State st = ITERATE;
+  double res = 0;
+  history.clear();
+  do {
+    int rc = system_apply(P, x, aux.data());
+    if (rc != ALFD_OK) return rc;
+    sub_from(N, b, aux.data());
+    const double beta = std::sqrt(pdot(P, aux.data(), aux.data()));
+    res = beta;
+    st = sc.check(k, res);
+    if (k == 0) history.push_back(res);
+    if (c.log_level >= 2) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
+    if (st != ITERATE) break;
+    std::fill(H.begin(), H.end(), 0.0);
+    double a = beta;
+    int ny = 0;
+    for (int j = 0; j < m; ++j) {
+      if (a != 0.0) {
+        const double ia = 1.0 / a;
+        for (int64_t i = 0; i < N; ++i) V[j][i] = ia * aux[i];
+      } else {
+        std::fill(V[j].begin(), V[j].end(), 0.0);
+      }
+      rc = precond_apply(P, V[j].data(), Z[j].data());
+      if (rc != ALFD_OK) return rc;
+      rc = system_apply(P, Z[j].data(), aux.data());
+      if (rc != ALFD_OK) return rc;
+      H[(size_t)0 * m + j] = pdot(P, aux.data(), V[0].data());
+      for (int i = 0; i < j; ++i) {
+        axpy(N, -H[(size_t)i * m + j], V[i].data(), aux.data());
+        H[(size_t)(i + 1) * m + j] = pdot(P, aux.data(), V[i + 1].data());
+      }
+      axpy(N, -H[(size_t)j * m + j], V[j].data(), aux.data());
+      H[(size_t)(j + 1) * m + j] = a = std::sqrt(pdot(P, aux.data(), aux.data()));
+      if (j > 0) {
+        res = hessenberg_lsq(H, m, j, beta, y);
+        ny = j;
+        ++k;
+        st = sc.check(k, res);
+        history.push_back(res);
+        if (c.log_level >= 2) std::printf("DEAL:FGMRES::Check %d\t%.17g\n", k, res);
+        if (st != ITERATE) break;
+      }
+    }
+    for (int i = 0; i < ny; ++i) axpy(N, y[i], Z[i].data(), x);
+  } while (st == ITERATE);
+  out->outer_iterations = k;
+  out->initial_residual = sc.initial;
+  out->last_residual = res;
+  if (st != SUCCESS) return std::isnan(res) ? ALFD_E_BREAKDOWN : ALFD_E_NO_CONVERGENCE_OUTER;
+  return ALFD_OK;
+}
+
 // deal.II SolverMinRes [EXT] (preconditioned MINRES with the Lanczos three-term
 // recurrence; r_l2 is the preconditioned residual estimate the stop rule sees).
 // Used at immersed_laplace.cc:629-631 and stokes...:1057-1064.
@@ -1451,8 +1546,9 @@ int orc_solve(const orc_problem *op, const alfd_config *cfg, const double *const
   pack(P, x, xx);
   std::memset(res, 0, sizeof(*res));
   const auto t0 = std::chrono::steady_clock::now();
-  rc = cfg->outer_solver == ALFD_OUTER_MINRES ? orc::minres(P, bb.data(), xx.data(), res, hist)
-                                             : orc::fgmres(P, bb.data(), xx.data(), res, hist);
+  rc = cfg->outer_solver == ALFD_OUTER_MINRES               ? orc::minres(P, bb.data(), xx.data(), res, hist)
+       : cfg->fgmres_flavour == ALFD_FGMRES_DEALII_95 ? orc::fgmres_dealii95(P, bb.data(), xx.data(), res, hist)
+                                                      : orc::fgmres(P, bb.data(), xx.data(), res, hist);
   res->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   unpack(P, xx, x);
   fill_result(P, res, rc);

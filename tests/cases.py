@@ -146,6 +146,13 @@ def case(name):
             cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
         else:
             cfg.w_inverse = _abi.W_MASS_INV_SQUARED
+    elif name == "stokes3d_fgmres95":
+        # deal.II <= 9.5 SolverFGMRES loop (alfd_fgmres_flavour): MGS, delayed least-squares check; restart 5
+        # forces several cycles so that the per-cycle counting rule (m - 1 steps per m applications) shows
+        pb = problems.stokes3d_sphere(6, 0)
+        cfg = _abi.default_config(_abi.AL_STOKES)
+        cfg.fgmres_flavour = _abi.FGMRES_DEALII_95
+        cfg.restart = 5
     elif name == "stokes3d_bench_settings":
         # exactly bench.py's solver settings (multigrid: Chebyshev(3) over [lmax/64, lmax], Chebyshev(10)
         # coarsest solve, geometric aggregates a = 2 / min_coarse 600, inner cap 100 = prm:23) at small N
@@ -175,7 +182,8 @@ ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes
              "rational_minres", "stokes_minres_diag", "stokes3d_multilevel", "laplace3d_multilevel",
              "elliptic_modified_multilevel", "laplace2d_operator_form", "laplace2d_exact_w", "stokes2d_exact_w",
              "laplace2d_operator_form_exact_w", "elliptic_modified_exact_w", "elliptic_ideal_exact_w",
-             "elasticity_modified", "elasticity_modified_multilevel", "stokes3d_bench_settings"]
+             "elasticity_modified", "elasticity_modified_multilevel", "stokes3d_bench_settings",
+             "stokes3d_fgmres95"]
 
 
 def oracle_system(pb, cfg):
@@ -193,3 +201,47 @@ def prepared_rhs(osys, pb, cfg):
         rc, rhs = osys.augment_rhs(cfg, rhs)
         assert rc == 0
     return rhs
+
+
+def hanging_node_variant(pb, plane=None):
+    """What deal.II's AffineConstraints::condense leaves behind for one layer of hanging nodes
+    (stokes_immersed_boundary.cc:468-482 refines locally around the immersed body): every second node
+    of one x-plane of the Taylor-Hood velocity grid is constrained to the mean of its two y-neighbours,
+    u_h = (u_a + u_b) / 2.  With T = the interpolation from the unconstrained dofs, the condensed
+    operators are T^T A T (+ identity on the constrained rows), T^T Bt, B T, T^T Ct, C T, T^T f.
+    The result has NO tensor-grid structure to offer: rows next to the plane carry new values and
+    constrained rows hold a lone diagonal -- the input for the algebraic aggregator."""
+    import scipy.sparse as sp
+    P = pb.params
+    assert P["dim"] == 3 and P["degree"] == 2 and P["ncomp"] == 3
+    n1 = 2 * P["n_cells"] + 1
+    plane = n1 // 2 if plane is None else plane
+    n = pb.mats["A"].nrows
+    rows, cols, vals = [], [], []
+    constrained = np.zeros(n, bool)
+    for k in range(2, n1 - 2):
+        for j in range(3, n1 - 3, 2):                     # odd interior y-index: hanging
+            h = (k * n1 + j) * n1 + plane
+            a, b = h - n1, h + n1
+            for c in range(3):
+                constrained[3 * h + c] = True
+                rows += [3 * h + c, 3 * h + c]
+                cols += [3 * a + c, 3 * b + c]
+                vals += [0.5, 0.5]
+    free = np.nonzero(~constrained)[0]
+    T = sp.csr_matrix((np.concatenate([np.ones(free.size), vals]),
+                       (np.concatenate([free, rows]), np.concatenate([free, cols]))), shape=(n, n))
+    Dc = sp.diags(constrained.astype(float))
+    mats = dict(pb.mats)
+    A = (T.T @ pb.mats["A"].to_scipy() @ T + Dc).tocsr()
+    A.eliminate_zeros()
+    mats["A"] = problems.Csr.from_scipy(A)
+    for name in ("Bt", "Ct"):
+        m = (T.T @ pb.mats[name].to_scipy()).tocsr()
+        mats[name] = problems.Csr.from_scipy(m)
+    mats["B"], mats["C"] = mats["Bt"].transpose(), mats["Ct"].transpose()
+    vecs = dict(pb.vecs)
+    vecs["f"] = T.T @ pb.vecs["f"]
+    out = problems.SyntheticProblem(params=dict(pb.params), mats=mats, vecs=vecs)
+    out.n_constrained = int(constrained.sum())
+    return out

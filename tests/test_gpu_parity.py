@@ -507,3 +507,34 @@ def test_properties_cfg5_full_size(built):
     nr = pb.block_sizes[0]
     res = _full_size_properties(pb, cfg, rhs, aggs, (12, 12), False, False, scipy_rows=(nr // 2, nr // 2 + 200000))
     print(f"cfg5 n={n}: outer {res.outer_iterations}, inner {res.inner_iterations}, {res.solve_seconds:.1f} s")
+
+
+def test_algebraic_aggregates_on_condensed_operator_parity(built):
+    """ALFD_PREC_MULTILEVEL without grid metadata: the library builds every level's aggregates from the uploaded
+    A alone (alfd_build_aggregates) for an operator with a condensed layer of hanging nodes; the oracle gets the
+    same aggregates (alfd_get_aggregates) -- identical counts, history within 1e-10."""
+    pb = cases.hanging_node_variant(problems.stokes3d_sphere(8, 0))
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    cfg.inner.max_steps = 100                       # the reference's cap (parameters_stokes_3d.prm:23)
+    cfg.inner_prec = _abi.PREC_MULTILEVEL
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+    ctx = solver.Context(0)
+    try:
+        ctx.set_matrix(_abi.A, pb.mats["A"])
+        aggs = ctx.build_aggregates(block_size=3, threshold=0.02, max_aggregate_nodes=8, min_coarse=300)
+        assert len(aggs) >= 2 and aggs[0][1] < pb.mats["A"].nrows // 8
+        assert int((aggs[0][0] < 0).sum()) == int((np.diff(pb.mats["A"].row_ptr) == 1).sum())
+        solver.upload_problem(ctx, pb, cfg, None)       # keeps the aggregates built above
+        rhs = ctx.augment_rhs(cases.rhs_of(pb))
+        x, res = ctx.solve(rhs)
+        hist = ctx.history()
+        osys = oracle.system_from_problem(pb, aggregates=aggs)
+        rc, orhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+        rc, ox, ores, ohist = osys.solve(cfg, orhs)
+        assert rc == 0 and res.status == 0
+        assert (res.outer_iterations, res.inner_iterations, res.mp_iterations) == \
+            (ores.outer_iterations, ores.inner_iterations, ores.mp_iterations)
+        assert np.max(np.abs(hist - ohist) / np.abs(ohist)) <= HIST_RTOL
+        assert res.outer_iterations <= 14
+    finally:
+        ctx.close()

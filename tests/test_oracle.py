@@ -422,3 +422,71 @@ def test_exact_w_inverse_matches_sparse_direct():
     cfg.w_inverse = _abi.W_MASS_INV_SQUARED
     rc, _, _ = cases.oracle_system(pb, cfg).precond_apply(cfg, cases.rng_blocks(pb, 1))
     assert rc == _abi.E_UNSUPPORTED
+
+
+def test_algebraic_aggregation_on_a_condensed_operator():
+    """alfd_host_aggregate_level (the library's aggregator, host side) on an operator WITHOUT grid
+    structure: one layer of hanging nodes condensed into the Taylor-Hood blocks (cases.hanging_node_variant).
+    Constrained and Dirichlet rows stay out, the components of a node share an aggregate, coarse ids are
+    contiguous, the result is deterministic -- and the oracle's multilevel preconditioner built on it beats the
+    single-level sweep."""
+    from fictitious_domain_al_preconditioners_amd import solver
+    pb = cases.hanging_node_variant(problems.stokes3d_sphere(8, 0))
+    a = pb.mats["A"]
+    agg, nc = solver.host_aggregate_level(a, 3, 0.02, 8)
+    agg2, nc2 = solver.host_aggregate_level(a, 3, 0.02, 8)
+    assert nc == nc2 and np.array_equal(agg, agg2)
+    lone = np.diff(a.row_ptr) == 1                      # identity rows: Dirichlet + constrained
+    assert pb.n_constrained == 234 and np.array_equal(agg < 0, lone)
+    nodes = agg.reshape(-1, 3)
+    inside = nodes[:, 0] >= 0
+    assert np.all(nodes[inside] % 3 == np.arange(3)) and np.all(np.diff(nodes[inside] // 3, axis=1) == 0)
+    assert np.array_equal(np.unique(agg[agg >= 0]), np.arange(nc)) and nc < a.nrows // 8
+    counts = {}
+    for prec in ("cheb", "ml"):
+        cfg = _abi.default_config(_abi.AL_STOKES)
+        cfg.inner.max_steps = 2000
+        aggs = None
+        if prec == "ml":
+            cfg.inner_prec = _abi.PREC_MULTILEVEL
+            cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+            aggs = [(agg, nc)]
+        osys = oracle.system_from_problem(pb, aggregates=aggs)
+        rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+        rc, x, res, hist = osys.solve(cfg, rhs)
+        assert rc == 0 and res.outer_iterations <= 14
+        counts[prec] = res.inner_iterations
+        # the condensed system is really solved: constrained dofs decouple (identity rows, zero rhs)
+        assert np.abs(x[0][lone]).max() == 0.0
+    assert counts["ml"] < counts["cheb"]
+
+
+def test_fgmres_flavours_agree_on_the_solution_and_differ_in_counting():
+    """deal.II <= 9.5 vs >= 9.6 SolverFGMRES [EXT]: same Krylov method, different bookkeeping.  Both reach the
+    stop rule and the same solution; with one cycle the 9.5 loop reports the same count as 9.6 while spending
+    one more preconditioner application (its least-squares check lags one Arnoldi vector); with restarts each
+    cycle of m applications advances its counter by m - 1."""
+    pb = problems.stokes3d_sphere(6, 0)
+    osys = oracle.system_from_problem(pb)
+    out = {}
+    for flavour in (_abi.FGMRES_DEALII_96, _abi.FGMRES_DEALII_95):
+        for restart in (30, 5):
+            cfg = _abi.default_config(_abi.AL_STOKES)
+            cfg.inner.max_steps = 1000
+            cfg.fgmres_flavour, cfg.restart = flavour, restart
+            rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+            rc, x, res, hist = osys.solve(cfg, rhs)
+            assert rc == 0 and res.last_residual <= max(cfg.outer.tol, cfg.outer.reduce * res.initial_residual)
+            assert len(hist) == res.outer_iterations + 1
+            out[flavour, restart] = (res, x)
+    r96, x96 = out[_abi.FGMRES_DEALII_96, 30]
+    r95, x95 = out[_abi.FGMRES_DEALII_95, 30]
+    assert r95.outer_iterations == r96.outer_iterations
+    assert r95.precond_applications == r96.precond_applications + 1
+    for a, b in zip(x95, x96):
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-8 * np.abs(b).max())
+    r95s, _ = out[_abi.FGMRES_DEALII_95, 5]
+    cycles = -(-r95s.outer_iterations // 4)
+    assert r95s.precond_applications >= r95s.outer_iterations + cycles - 1
+    bad = _abi.default_config(_abi.AL_STOKES)
+    bad.fgmres_flavour, bad.restart = _abi.FGMRES_DEALII_95, 1       # library refuses; oracle not asked
