@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--ml-coarse-degree", type=int, default=10)
     ap.add_argument("--agg-a", type=int, default=2, help="nodes per aggregate edge (geometric aggregation)")
     ap.add_argument("--min-coarse", type=int, default=600, help="stop coarsening below this many unknowns")
+    ap.add_argument("--comm", choices=["rccl", "host"], default=os.environ.get("ALFD_BENCH_COMM", "rccl"),
+                    help="multi-GPU transport: RCCL over xGMI (default) or host buffers through a gloo group "
+                         "(alfd_comm_init_host; slower, for boxes where RCCL cannot start)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only-spmv", type=int, default=0,
                     help="skip the solve; run this many back-to-back A SpMV launches (for rocprofv3)")
@@ -104,9 +107,12 @@ def main():
     t0 = time.time()
     ctx = solver.Context(local_rank)
     if world > 1:
-        uid = [solver.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(rank, world, uid[0])
+        if args.comm == "host":
+            ctx.comm_init_torch(dist.new_group(backend="gloo"))
+        else:
+            uid = [solver.Context.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(rank, world, uid[0])
         ctx.set_partition(plan.offsets)
     if cfg.inner_prec == _abi.PREC_MULTILEVEL:
         ta = time.time()
@@ -220,6 +226,7 @@ def main():
                            f"levels {[lv[1] for lv in levels]}"),
             "inner_max_steps": cfg.inner.max_steps,
             "restart": cfg.restart, "partition": f"row-slabs x{world}",
+            "transport": ("rccl" if args.comm == "rccl" else "host buffers over gloo") if world > 1 else None,
         },
         "roofline": {
             "bound": "hbm",

@@ -173,6 +173,10 @@ struct alfd_ctx {
   int rank = 0, nranks = 1;
   ncclComm_t nccl = nullptr;
   struct alfd_local_group *local = nullptr;  // in-process rank group (single-GPU emulation of N ranks)
+  alfd_host_allgather_fn host_allgather = nullptr;   // host-transport rank group (MPI / gloo launchers)
+  alfd_host_alltoallv_fn host_alltoallv = nullptr;
+  void *host_user = nullptr;
+  std::vector<char> host_send, host_recv;
   std::vector<std::vector<int64_t>> part;  // [block][nranks+1] global offsets
   // layout
   int nblocks = 0;
@@ -296,6 +300,17 @@ static int comm_allgather(alfd_ctx *ctx, const void *send, void *recv, size_t by
     g->barrier();
     return ALFD_OK;
   }
+  if (ctx->host_allgather) {
+    ctx->host_send.resize(bytes);
+    ctx->host_recv.resize(bytes * (size_t)ctx->nranks);
+    HIPC(hipMemcpyAsync(ctx->host_send.data(), send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    if (ctx->host_allgather(ctx->host_user, ctx->host_send.data(), ctx->host_recv.data(), bytes) != 0)
+      return ctx->err = "host all-gather callback failed", ALFD_E_COMM;
+    HIPC(hipMemcpyAsync(recv, ctx->host_recv.data(), ctx->host_recv.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next collective
+    return ALFD_OK;
+  }
   if (ncclAllGather(send, recv, bytes, ncclChar, ctx->nccl, ctx->stream) != ncclSuccess)
     return ctx->err = "ncclAllGather failed", ALFD_E_COMM;
   return ALFD_OK;
@@ -320,6 +335,18 @@ static int comm_alltoallv(alfd_ctx *ctx, const void *sendbuf, const int64_t *sen
     }
     HIPC(hipStreamSynchronize(ctx->stream));
     g->barrier();
+    return ALFD_OK;
+  }
+  if (ctx->host_alltoallv) {
+    const size_t ns = (size_t)send_off[ctx->nranks] * es, nr = (size_t)recv_off[ctx->nranks] * es;
+    ctx->host_send.resize(std::max<size_t>(ns, 1));
+    ctx->host_recv.resize(std::max<size_t>(nr, 1));
+    if (ns) HIPC(hipMemcpyAsync(ctx->host_send.data(), sendbuf, ns, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    if (ctx->host_alltoallv(ctx->host_user, ctx->host_send.data(), send_off, ctx->host_recv.data(), recv_off, es) != 0)
+      return ctx->err = "host all-to-all callback failed", ALFD_E_COMM;
+    if (nr) HIPC(hipMemcpyAsync(recvbuf, ctx->host_recv.data(), nr, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
     return ALFD_OK;
   }
   if (ncclGroupStart() != ncclSuccess) return ctx->err = "ncclGroupStart", ALFD_E_COMM;
@@ -586,7 +613,7 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
   if (!m.present) return ctx->err = "matrix not set", ALFD_E_NOT_SETUP;
   // RCCL send/recv pairs can be skipped by ranks with nothing to exchange; the
   // barrier-based in-process group needs every rank in every exchange.
-  if (ctx->nranks > 1 && !m.rep && (ctx->local || m.n_halo > 0 || m.send_off.back() > 0))
+  if (ctx->nranks > 1 && !m.rep && (ctx->local || ctx->host_alltoallv || m.n_halo > 0 || m.send_off.back() > 0))
     RC(halo_exchange(ctx, m, x));
   if (m.sparse && epi != 1) {
     // rows outside the list are structurally empty: their result is 0
@@ -1979,7 +2006,7 @@ static int diag_plus_m(alfd_ctx *ctx, const DevCsr &A, DevCsr &R, double g, int6
   }
 #undef ALFD_DIAG
   // a rank with no rows of R of its own may still own W entries its peers need
-  if (ctx->nranks > 1 && (ctx->local || R.n_halo > 0 || R.send_off.back() > 0))
+  if (ctx->nranks > 1 && (ctx->local || ctx->host_alltoallv || R.n_halo > 0 || R.send_off.back() > 0))
     RC(halo_exchange(ctx, R, ctx->diag[ALFD_INVW]));
   if (R.n_list > 0)
     hipLaunchKernelGGL(aug_diag_rows_kernel, dim3((unsigned)((R.n_list + 255) / 256)), dim3(256), 0,
@@ -2294,7 +2321,7 @@ static int exchange_ids(alfd_ctx *ctx, DevCsr &m, const std::vector<int32_t> &ow
   HIPC(hipMalloc((void **)&d, std::max<size_t>(v.size(), 1) * sizeof(double)));
   HIPC(hipMemcpyAsync(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   int rc = ALFD_OK;
-  if (ctx->local || m.n_halo > 0 || m.send_off.back() > 0) rc = halo_exchange(ctx, m, d);
+  if (ctx->local || ctx->host_alltoallv || m.n_halo > 0 || m.send_off.back() > 0) rc = halo_exchange(ctx, m, d);
   if (rc == ALFD_OK && m.n_halo > 0) {
     std::vector<double> h(m.n_halo);
     hipMemcpyAsync(h.data(), m.halo, m.n_halo * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
@@ -3095,6 +3122,19 @@ int alfd_comm_init_local(alfd_ctx_t ctx, alfd_local_group *g, int rank) {
   ctx->rank = rank;
   ctx->nranks = g->n;
   ctx->local = g->n > 1 ? g : nullptr;
+  return ALFD_OK;
+}
+
+int alfd_comm_init_host(alfd_ctx_t ctx, int rank, int nranks, alfd_host_allgather_fn allgather,
+                        alfd_host_alltoallv_fn alltoallv, void *user) {
+  CHECK_CTX();
+  if (nranks < 1 || rank < 0 || rank >= nranks || !allgather || !alltoallv) return ALFD_E_INVALID;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  if (nranks == 1) return ALFD_OK;
+  ctx->host_allgather = allgather;
+  ctx->host_alltoallv = alltoallv;
+  ctx->host_user = user;
   return ALFD_OK;
 }
 

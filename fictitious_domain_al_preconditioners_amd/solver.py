@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "alfd_local_group_destroy", "alfd_comm_init_local", "alfd_set_aggregates",
     "alfd_set_aggregate_partition", "alfd_get_matrix_info", "alfd_bench_spmv_format",
     "alfd_host_window_plan", "alfd_set_tunable", "alfd_build_aggregates", "alfd_get_aggregates",
-    "alfd_host_aggregate_level",
+    "alfd_host_aggregate_level", "alfd_comm_init_host",
 ]
 
 
@@ -99,6 +99,7 @@ def load_library():
         "alfd_build_aggregates": (C.c_int, [vp, i32, dbl, i32, i64, i32, C.POINTER(i32)]),
         "alfd_get_aggregates": (C.c_int, [vp, C.c_int, vp, i64, C.POINTER(i64), C.POINTER(i64)]),
         "alfd_host_aggregate_level": (C.c_int, [i64, vp, vp, vp, i32, dbl, i32, vp, C.POINTER(i64)]),
+        "alfd_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -156,6 +157,16 @@ class Context:
 
     def comm_init_local(self, group, rank):
         self._ck(self._lib.alfd_comm_init_local(self._h, group, rank))
+
+    def comm_init_torch(self, group=None):
+        """Multi-rank through torch.distributed HOST collectives (gloo or any CPU backend): the
+        library hands its all-gathers and neighbour exchanges to hostcomm's callbacks as host
+        buffers (alfd_comm_init_host).  One process per rank; library calls are collective."""
+        from . import hostcomm
+        rank, world, ag, a2a = hostcomm.torch_callbacks(group)
+        self._host_cbs = (ag, a2a)                               # keep the trampolines alive
+        self._ck(self._lib.alfd_comm_init_host(self._h, rank, world, C.cast(ag, C.c_void_p), C.cast(a2a, C.c_void_p),
+                                               None))
 
     def set_partition(self, offsets):
         arrs = [np.ascontiguousarray(o, np.int64) for o in offsets]

@@ -244,6 +244,20 @@ int alfd_local_group_create(int nranks, alfd_local_group **group);
 int alfd_local_group_destroy(alfd_local_group *group);
 int alfd_comm_init_local(alfd_ctx_t ctx, alfd_local_group *group, int rank);
 
+/* Host-transport rank group: the collectives of the row-partitioned path (one all-gather of a few
+ * scalars per reduction, one personalised neighbour exchange per halo) are handed to the caller as
+ * HOST buffers -- the library copies device -> host, calls back, copies host -> device.  For
+ * launchers whose ranks talk through MPI or gloo instead of RCCL (a deal.II program is an MPI
+ * program), and the vehicle of the two-process GPU test.  Both callbacks return 0 on success.
+ *   allgather: every rank contributes `bytes` bytes; recv holds nranks * bytes in rank order.
+ *   alltoallv: rank r sends send[send_off[p] .. send_off[p+1]) (elements of elem_size bytes) to p and
+ *              receives recv[recv_off[p] .. recv_off[p+1]) from p. */
+typedef int (*alfd_host_allgather_fn)(void *user, const void *send, void *recv, size_t bytes);
+typedef int (*alfd_host_alltoallv_fn)(void *user, const void *send, const int64_t *send_off, void *recv,
+                                      const int64_t *recv_off, size_t elem_size);
+int alfd_comm_init_host(alfd_ctx_t ctx, int rank, int nranks, alfd_host_allgather_fn allgather,
+                        alfd_host_alltoallv_fn alltoallv, void *user);
+
 /* Host-only halo plan of one row-partitioned matrix (no GPU, no communication):
  * rewrites the GLOBAL column indices of this rank's rows into the local index
  * space [owned columns | halo entries], lists the halo's global ids (sorted,

@@ -3,9 +3,10 @@
 Each rank generates only its row slab, builds the halo plan of every operator
 with the PRODUCT's host routine (alfd_host_halo_plan -- the one
 alfd_set_matrix runs before uploading), derives the send lists with the same
-protocol the library runs over RCCL (counts all-gather + id exchange), exchanges
-halo values point-to-point and applies the oracle's canonical SpMV to
-[owned | halo].  The result must equal, bit for bit, the rows of the
+protocol the library runs (counts all-gather + id exchange) and exchanges the halo
+values -- all through the product's host transport (hostcomm.torch_callbacks, the
+callbacks alfd_comm_init_host installs; RCCL carries the same calls on GPUs) -- and
+applies the oracle's canonical SpMV to [owned | halo].  The result must equal, bit for bit, the rows of the
 single-process SpMV; the rank-ordered sum of local dots must equal the
 oracle's emulated 2-rank dot."""
 import os
@@ -25,44 +26,37 @@ def _free_port():
     return p
 
 
-def _exchange(dist, rank, world, halo_globals, recv_off, col_offsets, x_local):
-    """Halo exchange with the library's protocol: (1) every rank announces how many
-    entries it wants from every owner, (2) owners receive the wanted global ids,
+def _exchange(cbs, rank, world, halo_globals, recv_off, col_offsets, x_local):
+    """Halo exchange with the library's protocol (upload_matrix / halo_exchange in csrc/alfd.hip), carried by
+    the PRODUCT's host transport (hostcomm.torch_callbacks -- the callbacks alfd_comm_init_host installs):
+    (1) all-gather of the per-owner request counts, (2) owners receive the wanted global ids,
     (3) owners send x[id - own_offset]."""
-    import torch
-    want_cnt = torch.tensor([int(recv_off[p + 1] - recv_off[p]) for p in range(world)], dtype=torch.int64)
-    all_cnt = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(all_cnt, want_cnt)
-    send_cnt = [int(all_cnt[p][rank]) for p in range(world)]      # what p wants from me
-    reqs, wanted = [], {}
+    import ctypes as C
+    ag, a2a = cbs
+
+    def ptr(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def offs(a):
+        return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+    recv_off = np.ascontiguousarray(recv_off, np.int64)
+    want_cnt = np.diff(recv_off).astype(np.int32)
+    all_cnt = np.zeros(world * world, np.int32)
+    assert ag(None, ptr(want_cnt), ptr(all_cnt), want_cnt.nbytes) == 0
+    send_off = np.zeros(world + 1, np.int64)
     for p in range(world):
-        if p == rank:
-            continue
-        if want_cnt[p] > 0:
-            ids = torch.from_numpy(halo_globals[recv_off[p]:recv_off[p + 1]].astype(np.int64))
-            reqs.append(dist.isend(ids, p))
-        if send_cnt[p] > 0:
-            wanted[p] = torch.zeros(send_cnt[p], dtype=torch.int64)
-            reqs.append(dist.irecv(wanted[p], p))
-    for r in reqs:
-        r.wait()
-    halo = np.zeros(len(halo_globals))
-    reqs, bufs = [], {}
+        send_off[p + 1] = send_off[p] + all_cnt[p * world + rank]        # what p wants from me
+    ids = np.ascontiguousarray(halo_globals, np.int32)
+    wanted = np.zeros(max(int(send_off[-1]), 1), np.int32)
+    assert a2a(None, ptr(ids), offs(recv_off), ptr(wanted), offs(send_off), 4) == 0
     c0 = int(col_offsets[rank])
-    for p in range(world):
-        if p == rank:
-            continue
-        if send_cnt[p] > 0:
-            vals = torch.from_numpy(x_local[wanted[p].numpy() - c0].copy())
-            reqs.append(dist.isend(vals, p))
-        if want_cnt[p] > 0:
-            bufs[p] = torch.zeros(int(want_cnt[p]), dtype=torch.float64)
-            reqs.append(dist.irecv(bufs[p], p))
-    for r in reqs:
-        r.wait()
-    for p, b in bufs.items():
-        halo[recv_off[p]:recv_off[p + 1]] = b.numpy()
-    return halo
+    vals = np.ascontiguousarray(x_local[wanted[:int(send_off[-1])] - c0], np.float64)
+    if vals.size == 0:
+        vals = np.zeros(1)
+    halo = np.zeros(max(len(halo_globals), 1))
+    assert a2a(None, ptr(vals), offs(send_off), ptr(halo), offs(recv_off), 8) == 0
+    return halo[:len(halo_globals)]
 
 
 def _worker(rank, world, port, q):
@@ -75,8 +69,10 @@ def _worker(rank, world, port, q):
         import sys
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, root)
-        from fictitious_domain_al_preconditioners_amd import _abi, partition, problems, solver
+        from fictitious_domain_al_preconditioners_amd import _abi, hostcomm, partition, problems, solver
         from oracle import oracle
+        r_, w_, ag, a2a = hostcomm.torch_callbacks()
+        assert (r_, w_) == (rank, world)
         n, ref = 6, 1
         plan = partition.slab_partition_stokes3d(n, ref, world)
         loc = problems.stokes3d_sphere(n, ref, row_ranges=plan.generator_ranges(rank))
@@ -91,7 +87,7 @@ def _worker(rank, world, port, q):
             offs = plan.offsets[colblock[name]]
             col_local, halo_globals, recv_off = solver.host_halo_plan(m.col, offs, rank)
             x_local = xg[colblock[name]][int(offs[rank]):int(offs[rank + 1])]
-            halo = _exchange(dist, rank, world, halo_globals, recv_off, offs, x_local)
+            halo = _exchange((ag, a2a), rank, world, halo_globals, recv_off, offs, x_local)
             x_ext = np.concatenate([x_local, halo])
             mloc = problems.Csr(m.nrows, x_ext.size, m.row_ptr, col_local, m.val)
             # lanes must follow the GLOBAL matrix' rule here; the library applies the
