@@ -229,6 +229,7 @@ struct alfd_ctx {
   double *t_lam = nullptr;                                                 // invW .* (C x)
   double *q_tmp = nullptr, *rhs_tmp = nullptr;                             // precond scratch
   double *V = nullptr, *Z = nullptr, *xb = nullptr, *bb = nullptr, *io = nullptr;
+  double *st_in = nullptr, *st_out = nullptr;   // staging of the depth-1 calls (the resident rhs / guess stay intact)
   double lambda_max = 0, lambda_min = 0;
   // stats of the current solve
   int64_t inner_its = 0, mp_its = 0;
@@ -2802,6 +2803,8 @@ static int setup(alfd_ctx *ctx) {
   RC(ws_alloc_zero(ctx, &ctx->xb, N));
   RC(ws_alloc_zero(ctx, &ctx->bb, N));
   RC(ws_alloc_zero(ctx, &ctx->io, N));
+  RC(ws_alloc_zero(ctx, &ctx->st_in, N));
+  RC(ws_alloc_zero(ctx, &ctx->st_out, N));
   for (int k = 0; k < 7; ++k) ctx->lam_max[k] = 0;
   if (ctx->n_sc_host) hipHostFree(ctx->n_sc_host), ctx->n_sc_host = nullptr;
   if (c.w_inverse != ALFD_W_DIAGONAL) {
@@ -3344,10 +3347,10 @@ int alfd_precond_apply(alfd_ctx_t ctx, const double *const *src, double *const *
   CHECK_SETUP();
   if (!src || !dst) return ALFD_E_INVALID;
   reset_stats(ctx);
-  RC(to_device(ctx, src, ctx->bb));
-  HIPC(hipMemsetAsync(ctx->io, 0, ctx->ntot() * sizeof(double), ctx->stream));
-  const int rc = precond_apply(ctx, ctx->bb, ctx->io);
-  RC(to_host(ctx, ctx->io, dst));
+  RC(to_device(ctx, src, ctx->st_in));
+  HIPC(hipMemsetAsync(ctx->st_out, 0, ctx->ntot() * sizeof(double), ctx->stream));
+  const int rc = precond_apply(ctx, ctx->st_in, ctx->st_out);
+  RC(to_host(ctx, ctx->st_out, dst));
   if (res) {
     std::memset(res, 0, sizeof(*res));
     fill_result(ctx, res, rc);
@@ -3359,10 +3362,10 @@ int alfd_system_apply(alfd_ctx_t ctx, const double *const *src, double *const *d
   CHECK_CTX();
   CHECK_SETUP();
   if (!src || !dst) return ALFD_E_INVALID;
-  RC(to_device(ctx, src, ctx->bb));
-  HIPC(hipMemsetAsync(ctx->io, 0, ctx->ntot() * sizeof(double), ctx->stream));
-  RC(system_apply(ctx, ctx->bb, ctx->io));
-  return to_host(ctx, ctx->io, dst);
+  RC(to_device(ctx, src, ctx->st_in));
+  HIPC(hipMemsetAsync(ctx->st_out, 0, ctx->ntot() * sizeof(double), ctx->stream));
+  RC(system_apply(ctx, ctx->st_in, ctx->st_out));
+  return to_host(ctx, ctx->st_out, dst);
 }
 
 int alfd_augment_rhs(alfd_ctx_t ctx, double *const *rhs) {
@@ -3372,10 +3375,10 @@ int alfd_augment_rhs(alfd_ctx_t ctx, double *const *rhs) {
   if (!ctx->diag[ALFD_INVW] || ctx->cfg.variant == ALFD_RATIONAL)
     return ctx->err = "rhs augmentation applies to the AL variants only", ALFD_E_UNSUPPORTED;
   const int last = ctx->nblocks - 1;
-  RC(to_device(ctx, rhs, ctx->bb));
-  RC(winv_scale(ctx, 1.0, ctx->bb + ctx->off[last], ctx->t_lam));
-  RC(spmv(ctx, ALFD_CT, ctx->t_lam, ctx->bb + ctx->off[0], 1, ctx->cfg.gamma));
-  return to_host(ctx, ctx->bb, rhs);
+  RC(to_device(ctx, rhs, ctx->st_in));
+  RC(winv_scale(ctx, 1.0, ctx->st_in + ctx->off[last], ctx->t_lam));
+  RC(spmv(ctx, ALFD_CT, ctx->t_lam, ctx->st_in + ctx->off[0], 1, ctx->cfg.gamma));
+  return to_host(ctx, ctx->st_in, rhs);
 }
 
 int alfd_upload_rhs(alfd_ctx_t ctx, const double *const *rhs, const double *const *x0) {

@@ -332,6 +332,9 @@ int alfd_augment_rhs(alfd_ctx_t ctx, double *const *rhs_blocks);
  * x_blocks: in = initial guess, out = solution. */
 int alfd_solve(alfd_ctx_t ctx, const double *const *rhs_blocks, double *const *x_blocks,
                alfd_result *res);
+/* (alfd_precond_apply, alfd_system_apply and alfd_augment_rhs stage their host vectors in buffers of
+ * their own: a right-hand side / initial guess uploaded with alfd_upload_rhs stays intact, so the
+ * depth-1 calls may be mixed with alfd_solve_resident.) */
 /* Same solve with the vectors already resident in HBM (no PCIe in the timed
  * region): alfd_upload_rhs() then alfd_solve_resident() any number of times,
  * alfd_download_solution() at the end. */

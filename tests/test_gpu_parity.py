@@ -219,6 +219,21 @@ def test_solve_matches_oracle_and_golden(ctxs, name):
         assert np.linalg.norm(r) <= 10 * max(cfg.outer.tol, cfg.outer.reduce * res.initial_residual)
 
 
+def test_depth1_calls_leave_the_resident_rhs_alone(ctxs):
+    """vmult / AA.vmult between alfd_upload_rhs and alfd_solve_resident (adapter depth 1 mixed with depth 2)."""
+    pb, cfg, ctx, osys = ctxs("stokes3d_sphere")
+    rhs = cases.prepared_rhs(osys, pb, cfg)
+    x_ref, res_ref = ctx.solve(rhs)
+    ctx.upload_rhs(rhs)
+    ctx.precond_apply(cases.rng_blocks(pb, 5))
+    ctx.system_apply(cases.rng_blocks(pb, 6))
+    ctx.augment_rhs(cases.rhs_of(pb))
+    res = ctx.solve_resident()
+    assert res.outer_iterations == res_ref.outer_iterations and res.last_residual == res_ref.last_residual
+    for a, b in zip(ctx.download_solution(), x_ref):
+        assert np.array_equal(a, b)
+
+
 def test_minres_reference_shaped_classes(ctxs):
     pb, cfg, ctx, osys = ctxs("rational_minres")
     AA, P = solver.SystemOperator(ctx), solver.RationalPreconditioner(ctx)
