@@ -779,6 +779,11 @@ void build_immersed(const Params &P, const Grid &g, Problem &pb) {
     pb.mats["M"] = csr_slice_rows(Mx, P.l0, P.l1);
     pb.mats["K"] = csr_slice_rows(Kx, P.l0, P.l1);
     gv = std::vector<double>(gv.begin() + P.l0, gv.begin() + P.l1);
+    if (pb.mats.count("A2")) {   // elliptic interface: the immersed block shares the multiplier's row range
+      pb.mats["A2"] = csr_slice_rows(pb.mats["A2"], P.l0, P.l1);
+      std::vector<double> &f2 = pb.vecs["f2"];
+      f2 = std::vector<double>(f2.begin() + P.l0, f2.begin() + P.l1);
+    }
   } else {
     pb.mats["Ct"] = std::move(Ct);
     pb.mats["C"] = std::move(C);
@@ -974,13 +979,24 @@ void build_immersed_box3d(const Params &P, const Grid &g, Problem &pb) {
     for (int a = 0; a < 3; ++a) xyz[n * 3 + a] = P.box_lo[a] + idx[a] * h[a];
   }
   pb.vecs["n_lambda_global"] = {(double)(nl * nc)};
-  pb.mats["Ct"] = csr_transpose(C);
-  pb.mats["C"] = std::move(C);
-  pb.mats["M"] = std::move(Mx);
-  pb.mats["K"] = std::move(Kx);
-  pb.mats["A2"] = std::move(A2);
-  pb.vecs["g"] = std::move(gv);
-  pb.vecs["f2"] = std::move(f2);
+  Csr Ct = csr_transpose(C);
+  if (P.u_node0 >= 0) {   // this rank's rows only (column indices stay global)
+    pb.mats["Ct"] = csr_slice_rows(Ct, P.u_node0 * nc, P.u_node1 * nc);
+    pb.mats["C"] = csr_slice_rows(C, P.l0, P.l1);
+    pb.mats["M"] = csr_slice_rows(Mx, P.l0, P.l1);
+    pb.mats["K"] = csr_slice_rows(Kx, P.l0, P.l1);
+    pb.mats["A2"] = csr_slice_rows(A2, P.l0, P.l1);
+    pb.vecs["g"] = std::vector<double>(gv.begin() + P.l0, gv.begin() + P.l1);
+    pb.vecs["f2"] = std::vector<double>(f2.begin() + P.l0, f2.begin() + P.l1);
+  } else {
+    pb.mats["Ct"] = std::move(Ct);
+    pb.mats["C"] = std::move(C);
+    pb.mats["M"] = std::move(Mx);
+    pb.mats["K"] = std::move(Kx);
+    pb.mats["A2"] = std::move(A2);
+    pb.vecs["g"] = std::move(gv);
+    pb.vecs["f2"] = std::move(f2);
+  }
   pb.vecs["immersed_xyz"] = std::move(xyz);
 }
 
@@ -1025,8 +1041,7 @@ bool generate(Problem &pb) {
   }
   if (P.elasticity && (P.ncomp != P.dim || P.dim != 3 || P.stokes || P.degree != 1))
     return pb.err = "elasticity needs dim 3, degree 1, ncomp 3, stokes off", false;
-  if (P.u_node0 >= 0 && P.immersed_kind >= 1)
-    return pb.err = "row ranges are not implemented for the box-immersed (elliptic interface) problems", false;
+
   Grid g;
   g.dim = P.dim;
   g.p = P.degree;

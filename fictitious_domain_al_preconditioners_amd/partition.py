@@ -54,6 +54,16 @@ def slab_partition(dim: int, n_cells: int, n_lambda: int, world: int, ncomp: int
     return SlabPlan(world, sizes, offsets, nu, npn, ncomp)
 
 
+def slab_partition_interface(dim: int, n_cells: int, n_immersed_nodes: int, world: int, ncomp: int = 1) -> SlabPlan:
+    """elliptic_interface / elasticity (problems.elliptic_interface2d, problems.elasticity3d): background Q1 nodes in
+    z-slabs (y-rows in 2-D), the immersed unknowns and the multipliers -- two blocks of the same size -- split evenly
+    by node with the SAME offsets (M maps between them)."""
+    base = slab_partition(dim, n_cells, n_immersed_nodes * ncomp, world, ncomp, stokes=False)
+    fg = np.array([(r * n_immersed_nodes) // world for r in range(world + 1)], np.int64) * ncomp
+    offsets = [base.offsets[0], fg, fg.copy()]
+    return SlabPlan(world, [int(o[-1]) for o in offsets], offsets, base.node_offsets_u, base.node_offsets_u, ncomp)
+
+
 def slab_partition_stokes3d(n_cells: int, immersed_refine: int, world: int) -> SlabPlan:
     """The bench workload: 3-D Taylor-Hood + cubed sphere (problems.stokes3d_sphere)."""
     n_lambda = 3 * (6 * 4 ** immersed_refine + 2)

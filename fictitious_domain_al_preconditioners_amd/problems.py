@@ -179,8 +179,8 @@ class SyntheticProblem:
     def inv_w_diag_of_mass_squared(self) -> np.ndarray:
         """W^-1 = 1 / (M M)_ii, the true diagonal of M^2 (utilities.h:348-374,
         elliptic_interface.cc:726)."""
-        m = self.mats["M"].to_scipy()
-        return 1.0 / np.asarray(m.multiply(m.T).sum(axis=1)).ravel()
+        m = self.mats["M"]          # M is symmetric: (M M)_ii = sum_k M_ik^2, row-local (works on a row slice)
+        return 1.0 / np.add.reduceat(m.val * m.val, m.row_ptr[:-1])
 
     def rho_bound(self) -> float:
         """||A_Gamma||_inf / min_i M_ii (immersed_laplace.cc:609-614)."""
@@ -314,7 +314,7 @@ def stokes2d_circle(n_cells=32, immersed_refine=4, gamma_grad_div=10.0, coupling
                     body_force=(1.0, 0.0), embedded_value=(-1.0, 1.0))
 
 
-def elliptic_interface2d(n_bg=64, n_fg=16, beta1=1.0, beta2=10.0, coupling_nq=3) -> SyntheticProblem:
+def elliptic_interface2d(n_bg=64, n_fg=16, beta1=1.0, beta2=10.0, coupling_nq=3, row_ranges=None) -> SyntheticProblem:
     """cfg 3: elliptic_interface 2-D + parameters_elliptic_interface/parameters_modified.prm.
     Background Q1 on n_bg^2 cells of [-1,1]^2 (prm:53-54), immersed Q1 on n_fg^2 cells of
     [-0.14,0.47]^2 (prm:55-56), A = beta_1 stiffness, A2 = (beta_2 - beta_1) stiffness
@@ -322,11 +322,11 @@ def elliptic_interface2d(n_bg=64, n_fg=16, beta1=1.0, beta2=10.0, coupling_nq=3)
     prm (:5); BASELINE.json quotes a jump of 1e3 -- both are valid inputs."""
     return generate(dim=2, degree=1, ncomp=1, n_cells=n_bg, lo=-1.0, hi=1.0, beta=beta1,
                     coupling_nq=coupling_nq, body_force=(1.0,), embedded_value=(0.0,),
-                    immersed_box=(-0.14, 0.47, n_fg), beta2=beta2 - beta1)
+                    immersed_box=(-0.14, 0.47, n_fg), beta2=beta2 - beta1, row_ranges=row_ranges)
 
 
 def elasticity3d(n_bg=16, cells_fg=None, lame_bg=(2.0, 1.0), lame_fg=(20.0, 10.0), coupling_nq=2,
-                 box=((-0.65, -0.3, -0.4), (0.65, 0.3, 0.4)), mesh_ratio=2.0) -> SyntheticProblem:
+                 box=((-0.65, -0.3, -0.4), (0.65, 0.3, 0.4)), mesh_ratio=2.0, row_ranges=None) -> SyntheticProblem:
     """cfg 5: elliptic_interface 3-D elasticity, parameters_elliptic_interface/elasticity.prm.
     Background vector-Q1 on n_bg^3 cells of [-1.25, 1.25]^3 (prm:55) with lambda, mu = 2, 1
     (prm:25,27); immersed hyper_rectangle [-.65,.65] x [-.3,.3] x [-.4,.4] (prm:56-57) of trilinear
@@ -346,7 +346,7 @@ def elasticity3d(n_bg=16, cells_fg=None, lame_bg=(2.0, 1.0), lame_fg=(20.0, 10.0
     return generate(dim=3, degree=1, ncomp=3, n_cells=n_bg, lo=-1.25, hi=1.25, coupling_nq=coupling_nq,
                     body_force=(1.0, 1.0, 1.0), embedded_value=(0.0, 0.0, 0.0),
                     elasticity=(lame_bg[0], lame_bg[1], jump[0], jump[1]),
-                    immersed_box3d=(box[0], box[1], cells_fg))
+                    immersed_box3d=(box[0], box[1], cells_fg), row_ranges=row_ranges)
 
 
 def geometric_aggregates(pb: SyntheticProblem, a: int = 2, min_coarse: int = 600, max_levels: int = 7):

@@ -206,3 +206,63 @@ def test_rank_without_multiplier_rows(built):
     for b in range(3):
         xs = np.concatenate([out[r]["x"][b] for r in range(world)])
         assert np.allclose(xs, ox[b], rtol=1e-9, atol=1e-10 * max(np.abs(ox[b]).max(), 1e-30))
+
+
+def _run_interface_ranks(world, plan, make_local, cfg):
+    group = solver.LocalGroup(world)
+    out = [None] * world
+    errs = []
+
+    def work(rank):
+        try:
+            pb = make_local(plan.generator_ranges(rank))
+            ctx = solver.Context(0)
+            ctx.comm_init_local(group.handle, rank)
+            ctx.set_partition(plan.offsets)
+            solver.upload_problem(ctx, pb, cfg)
+            x, res = ctx.solve(cases.rhs_of(pb))
+            out[rank] = dict(x=x, res=res.as_dict(), hist=ctx.history())
+            ctx.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    group.close()
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("name,world", [("elliptic_modified", 2), ("elliptic_ideal", 3), ("elliptic_modified_exact_w", 2),
+                                        ("elasticity_modified", 3)])
+def test_partitioned_interface_problems_match_oracle_emulation(built, name, world):
+    """The elliptic-interface / elasticity systems (BASELINE cfg 3 and 5) row-partitioned: background slabs, the
+    immersed block and the multiplier block split with the SAME offsets (M maps between them), the 2x2 block CG of the
+    ideal variant with its dots over [u | u2], the nested mass solves of the exact W^-1 -- counts equal to the oracle's
+    emulation of the partition, history within 1e-10, stitched solution equal."""
+    full, cfg = cases.case(name)
+    P = full.params
+    n_fg_nodes = full.block_sizes[1] // P["ncomp"]
+    plan = partition.slab_partition_interface(P["dim"], P["n_cells"], n_fg_nodes, world, ncomp=P["ncomp"])
+    if name.startswith("elasticity"):
+        make_local = lambda rr: problems.elasticity3d(P["n_cells"], row_ranges=rr)
+    else:
+        n_fg = int(round(np.sqrt(n_fg_nodes))) - 1
+        beta2 = 10.0
+        make_local = lambda rr: problems.elliptic_interface2d(P["n_cells"], n_fg, beta2=beta2, row_ranges=rr)
+    out = _run_interface_ranks(world, plan, make_local, cfg)
+    osys = oracle.system_from_problem(full, nranks_emulated=world, part_offsets=plan.offsets)
+    rc, ox, ores, ohist = osys.solve(cfg, cases.rhs_of(full))
+    assert rc == 0
+    for r in range(world):
+        res = out[r]["res"]
+        assert res["status"] == 0
+        assert (res["outer_iterations"], res["inner_iterations"], res["mass_iterations"]) == \
+            (ores.outer_iterations, ores.inner_iterations, ores.mass_iterations)
+        assert np.max(np.abs(out[r]["hist"] - ohist) / np.abs(ohist)) <= 1e-10
+    for b in range(3):
+        xs = np.concatenate([out[r]["x"][b] for r in range(world)])
+        assert np.allclose(xs, ox[b], rtol=1e-8, atol=1e-9 * max(np.abs(ox[b]).max(), 1e-30))
