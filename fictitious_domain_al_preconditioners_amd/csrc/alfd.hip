@@ -3650,6 +3650,15 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   return ALFD_OK;
 }
 
+int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_bytes) {
+  CHECK_CTX();
+  size_t f = 0, t = 0;
+  HIPC(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return ALFD_OK;
+}
+
 int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value) {
   if (!ctx || !name) return ALFD_E_INVALID;
   if (std::strcmp(name, "value_index") == 0) {

@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "alfd_set_aggregate_partition", "alfd_get_matrix_info", "alfd_bench_spmv_format",
     "alfd_host_window_plan", "alfd_set_tunable", "alfd_build_aggregates", "alfd_get_aggregates",
     "alfd_host_aggregate_level", "alfd_comm_init_host",
+    "alfd_get_device_memory",
 ]
 
 
@@ -100,6 +101,7 @@ def load_library():
         "alfd_get_aggregates": (C.c_int, [vp, C.c_int, vp, i64, C.POINTER(i64), C.POINTER(i64)]),
         "alfd_host_aggregate_level": (C.c_int, [i64, vp, vp, vp, i32, dbl, i32, vp, C.POINTER(i64)]),
         "alfd_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
+        "alfd_get_device_memory": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -315,6 +317,12 @@ class Context:
     def set_tunable(self, name, value):
         """Run-time switch (alfd_set_tunable), e.g. ("value_index", 0): general-matrix SpMV kernel."""
         self._ck(self._lib.alfd_set_tunable(self._h, name.encode(), int(value)))
+
+    def device_memory(self):
+        """(free, total) bytes of the context's GPU."""
+        f, t = C.c_int64(0), C.c_int64(0)
+        self._ck(self._lib.alfd_get_device_memory(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def enable_timing(self, on=True):
         self._ck(self._lib.alfd_enable_timing(self._h, int(on)))

@@ -387,6 +387,8 @@ int alfd_host_window_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *
  * matrix through the 10 B/nnz window kernel); streamed_bytes as in alfd_matrix_info. */
 int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value_index,
                            double *ms_per_launch, double *streamed_bytes);
+/* Free / total bytes of the context's device (hipMemGetInfo): leak checks, capacity planning. */
+int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_bytes);
 /* Run-time switches of a context (measurement and A/B comparison; results never change):
  *   "value_index"  1 (default): matrices whose row blocks were dictionary-coded at upload use the
  *                  3 B/nnz kernel; 0: every windowed matrix goes through the general 10 B/nnz kernel
