@@ -77,7 +77,7 @@ class Result(C.Structure):
 
 class MatrixInfo(C.Structure):
     _fields_ = [
-        ("lanes", C.c_int32), ("windowed", C.c_int32), ("value_indexed", C.c_int32), ("reserved", C.c_int32),
+        ("lanes", C.c_int32), ("windowed", C.c_int32), ("value_indexed", C.c_int32), ("batch_major", C.c_int32),
         ("nnz", C.c_int64), ("window_blocks", C.c_int64), ("window_fallback_blocks", C.c_int64),
         ("value_indexed_blocks", C.c_int64), ("value_indexed_nnz", C.c_int64),
         ("dictionary_entries", C.c_int64), ("value_wide_nnz", C.c_int64),
@@ -91,6 +91,14 @@ class WindowPlanInfo(C.Structure):
         ("blocks", C.c_int64), ("fallback_blocks", C.c_int64), ("segments", C.c_int64),
         ("value_indexed_blocks", C.c_int64), ("value_indexed_nnz", C.c_int64), ("value_wide_nnz", C.c_int64),
         ("dictionary_entries", C.c_int64), ("batches", C.c_int64), ("decode_mismatches", C.c_int64),
+    ]
+
+
+class StreamPlanInfo(C.Structure):
+    _fields_ = [
+        ("ok", C.c_int32), ("max_window", C.c_int32), ("max_rows", C.c_int32), ("max_batches", C.c_int32),
+        ("blocks", C.c_int64), ("batches", C.c_int64), ("segments", C.c_int64), ("dictionary_entries", C.c_int64),
+        ("stream_bytes", C.c_int64), ("decode_mismatches", C.c_int64), ("rows_covered", C.c_int64),
     ]
 
 

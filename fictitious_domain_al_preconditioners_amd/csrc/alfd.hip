@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -35,6 +36,7 @@
 
 #include "alfd/alfd.h"
 #include "kernels.hpp"
+#include "kernels_vs.hpp"
 
 namespace alfd {
 
@@ -93,9 +95,25 @@ struct DevCsr {
   int32_t *vib_cnt = nullptr;
   int32_t vib_stride = 0;
   int32_t *blk_seg_begin = nullptr, *blk_W = nullptr, *seg_col = nullptr, *seg_off = nullptr;
+  // batch-major format (spmv_vs_kernel, kernels_vs.hpp)
+  struct Vs {
+    bool on = false, bricks = false;
+    int64_t nb = 0, nseg = 0, stream_bytes = 0, nbatch = 0, dict_total = 0;
+    int32_t stride = 0, maxW = 0;
+    uint8_t *stream = nullptr;
+    int64_t *sb = nullptr;
+    uint64_t *tab = nullptr;
+    int32_t *cnt = nullptr, *seg_begin = nullptr, *blkW = nullptr, *seg_col = nullptr,
+            *seg_off = nullptr, *doff = nullptr, *dn = nullptr;
+    double *dict = nullptr;
+  } vs;
   // bytes the kernel in use moves per launch (format bytes, x read once)
-  double streamed_bytes(bool use_vi) const {
+  double streamed_bytes(bool use_vi, bool use_vs = false) const {
     const double vec = (double)(n_list + 1) * 8.0 + (double)n_list * 8.0 + (double)(sparse ? n_list : ncols) * 8.0;
+    if (vs.on && use_vs && use_vi)
+      return (double)vs.stream_bytes + 32.0 * (double)vs.nbatch + 28.0 * (double)vs.nb +
+             8.0 * (double)vs.nseg + 8.0 * (double)vs.dict_total + 8.0 * (double)nrows +
+             8.0 * (double)(sparse ? n_list : ncols);
     if (!win) return (double)nnz * 12.0 + vec;
     const double meta = (double)win_nblocks * 8.0 + (double)win_nseg * 8.0;
     if (!(vi && use_vi)) return (double)nnz * 10.0 + vec + meta;
@@ -253,6 +271,9 @@ struct alfd_ctx {
   int win_RB_vi = 96;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
   int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
+  int vs_enable = 0, vs_NW = 4, vs_RB = 96, vs_xcd = 0;   // batch-major format (alfd_set_tunable "batch_major")
+  std::vector<int64_t> rb_ptr[ALFD_NSLOTS + 1];   // row-block hint per slot (alfd_set_row_blocks)
+  std::vector<int32_t> rb_rows[ALFD_NSLOTS + 1];
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
   int64_t ntot() const { return off[nblocks]; }
 };
@@ -606,6 +627,31 @@ static bool launch_window_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, do
   return false;
 }
 
+
+static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
+                      const double *d, double *y2) {
+  const DevCsr::Vs &v = m.vs;
+  const int NW = ctx->vs_NW;
+  const size_t lds = (size_t)kVsWinOff + (size_t)v.maxW * sizeof(double);
+#define ALFD_VS(EPI, NWV)                                                                                       \
+  hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, NWV>), dim3((unsigned)v.nb), dim3(64 * NWV), lds, ctx->stream,   \
+                     v.stream, v.sb, v.tab, v.cnt, v.stride, v.seg_begin, v.blkW, v.seg_col, v.seg_off, v.doff, \
+                     v.dn, v.dict, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->vs_xcd)
+#define ALFD_VS_E(NWV)                  \
+  do {                                  \
+    if (epi == 0) ALFD_VS(0, NWV);      \
+    else if (epi == 1) ALFD_VS(1, NWV); \
+    else if (epi == 2) ALFD_VS(2, NWV); \
+    else ALFD_VS(3, NWV);               \
+  } while (0)
+  if (NW == 8) ALFD_VS_E(8);
+  else if (NW == 2) ALFD_VS_E(2);
+  else ALFD_VS_E(4);
+#undef ALFD_VS_E
+#undef ALFD_VS
+  return true;
+}
+
 static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x);
 
 // epi 0: y = A x; 1: y = fma(alpha, A x, y); 2: y = d .* (A x); 3: y = A x, y2 = d .* y
@@ -623,6 +669,10 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
   }
   if (m.n_list == 0) return ALFD_OK;
   Timer tm(ctx, cls, m.algorithmic_bytes());
+  if (m.vs.on && ctx->vs_enable && !ctx->vi_off && launch_vs(ctx, m, x, y, epi, alpha, d, y2)) {
+    HIPC(hipGetLastError());
+    return ALFD_OK;
+  }
   if (m.win && launch_window_RU(ctx, m, x, y, epi, alpha, d, y2)) {
     HIPC(hipGetLastError());
     return ALFD_OK;
@@ -1829,6 +1879,310 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
   return ALFD_OK;
 }
 
+
+// ---- batch-major format (kernels_vs.hpp): host planning, then upload.
+// Row blocks are lists of rows: runs of RB rows of the numbering, or the caller's blocks
+// (alfd_set_row_blocks: bricks of the mesh graph).  The format is all-or-nothing: every block
+// needs an x window of at most maxW slots, at most 256 distinct values, rows of at most
+// kVsMaxLen entries; otherwise the matrix keeps the formats of plan_window.
+struct VsPlan {
+  bool ok = false;
+  int64_t nb = 0, nbatch = 0;
+  int rbs = 0, stride = 0;
+  int32_t maxW = 0;
+  std::vector<int32_t> blkW, seg_begin, seg_col, seg_off, doff, dn, cnt;
+  std::vector<double> dict;
+  std::vector<int64_t> sb;
+  std::vector<uint8_t> stream;
+  std::vector<uint64_t> tab;
+};
+
+struct VsBatch {
+  int cls, nreal, id[4];
+};
+// class-sorted batches of one block (rows given by their block-local ids 0..nr-1 and lengths)
+static bool vs_batches(int nr, const int64_t *len, std::vector<VsBatch> &out) {
+  out.clear();
+  for (int cls = 0; cls <= 6; ++cls) {
+    const int R = 4;
+    VsBatch bt{cls, 0, {0, 0, 0, 0}};
+    for (int i = 0; i < nr; ++i) {
+      if (len[i] > kVsMaxLen) return false;
+      if ((int)((len[i] + 63) / 64) != cls) continue;
+      bt.id[bt.nreal++] = i;
+      if (bt.nreal == R) {
+        out.push_back(bt);
+        bt.nreal = 0;
+      }
+    }
+    if (bt.nreal) out.push_back(bt);
+  }
+  return true;
+}
+
+static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int RB, int maxW,
+                    int GAP, int64_t nb_in, const int64_t *bptr, const int32_t *brows, VsPlan &pl) {
+  const bool nat = bptr == nullptr;
+  const int64_t nb = nat ? (nrows + RB - 1) / RB : nb_in;
+  if (nb == 0 || nb > 2147483000LL) return;
+  auto blk_rows = [&](int64_t b, std::vector<int32_t> &rows) {
+    rows.clear();
+    if (nat) {
+      for (int64_t r = b * RB; r < std::min<int64_t>((b + 1) * RB, nrows); ++r) rows.push_back((int32_t)r);
+    } else {
+      rows.assign(brows + bptr[b], brows + bptr[b + 1]);
+    }
+  };
+  const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  // pass 1: batch counts and stream extents
+  std::vector<int64_t> blk_entries(nb, 0);
+  std::vector<int32_t> blk_nbatch(nb, 0), blk_nrows(nb, 0);
+  std::atomic<bool> bad(false);
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<int32_t> rows;
+        std::vector<int64_t> len;
+        std::vector<VsBatch> bts;
+        for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
+          blk_rows(b, rows);
+          if (rows.size() > (size_t)kVsMaxRows) { bad = true; break; }
+          len.resize(rows.size());
+          for (size_t i = 0; i < rows.size(); ++i) len[i] = rp[rows[i] + 1] - rp[rows[i]];
+          if (!vs_batches((int)rows.size(), len.data(), bts)) { bad = true; break; }
+          int64_t e = 0;
+          for (const VsBatch &q : bts) {
+            const int64_t full = q.cls > 0 ? 64 * (q.cls - 1) : 0;
+            int64_t l = 0;
+            for (int i = 0; i < q.nreal; ++i) l += len[q.id[i]] - full;
+            e += 4 * full + (l + 15) / 16 * 16;   // lane-major full chunks of 4 row slots + compact tail
+          }
+          blk_entries[b] = e;
+          blk_nbatch[b] = (int32_t)bts.size();
+          blk_nrows[b] = (int32_t)rows.size();
+        }
+      });
+    for (auto &x : th) x.join();
+  }
+  if (bad) return;
+  pl.nb = nb;
+  pl.sb.assign(nb, 0);
+  int64_t tot = 0;
+  int maxb = 1, maxr = 1;
+  for (int64_t b = 0; b < nb; ++b) {
+    pl.sb[b] = tot;
+    tot += 3 * blk_entries[b];
+    if (blk_entries[b] > 0xfffffLL) return;
+    maxb = std::max(maxb, (int)blk_nbatch[b]);
+    maxr = std::max(maxr, (int)blk_nrows[b]);
+    pl.nbatch += blk_nbatch[b];
+  }
+  if (maxb > 0xffff) return;
+  pl.stride = maxb;
+  pl.rbs = maxr;
+  pl.stream.assign((size_t)tot + 4096, 0);
+  pl.tab.assign((size_t)nb * maxb * 4, 0);
+  pl.cnt.assign(nb, 0);
+  pl.blkW.assign(nb, 0);
+  pl.dn.assign(nb, 0);
+  std::vector<int32_t> blk_nseg(nb, 0);
+  std::vector<std::vector<double>> t_dict(T);
+  std::vector<std::vector<int32_t>> t_seg_col(T), t_seg_off(T), t_doff(T);
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<int32_t> rows, pos;
+        std::vector<int64_t> len;
+        std::vector<VsBatch> bts;
+        std::vector<uint8_t> mark;
+        constexpr int kTab = 1024;
+        std::vector<uint64_t> keys(kTab);
+        std::vector<int16_t> ids(kTab);
+        for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
+          blk_rows(b, rows);
+          const int nr = (int)rows.size();
+          len.resize(nr);
+          int32_t clo = INT32_MAX, chi = -1;
+          for (int i = 0; i < nr; ++i) {
+            len[i] = rp[rows[i] + 1] - rp[rows[i]];
+            for (int64_t k = rp[rows[i]]; k < rp[rows[i] + 1]; ++k) {
+              clo = std::min(clo, col[k]);
+              chi = std::max(chi, col[k]);
+            }
+          }
+          vs_batches(nr, len.data(), bts);
+          pl.cnt[b] = (int32_t)bts.size();
+          t_doff[t].push_back((int32_t)t_dict[t].size());
+          // x window: maximal runs of used columns, gaps shorter than GAP bridged
+          const int64_t range = chi < 0 ? 0 : (int64_t)chi - clo + 1;
+          if (range > (int64_t)(1 << 24)) { bad = true; break; }
+          mark.assign(range, 0);
+          for (int i = 0; i < nr; ++i)
+            for (int64_t k = rp[rows[i]]; k < rp[rows[i] + 1]; ++k) mark[col[k] - clo] = 1;
+          pos.assign(range, -1);
+          int32_t W = 0, nseg = 0;
+          int64_t c = 0;
+          while (c < range) {
+            if (!mark[c]) {
+              ++c;
+              continue;
+            }
+            int64_t e = c, last = c;
+            while (e < range) {
+              if (mark[e]) last = e;
+              else if (e - last >= GAP) break;
+              ++e;
+            }
+            for (int64_t q0 = c; q0 <= last; q0 += 64) {   // pieces of at most 64 slots: one wave-load each
+              t_seg_col[t].push_back((int32_t)(clo + q0));
+              t_seg_off[t].push_back(W + (int32_t)(q0 - c));
+              ++nseg;
+            }
+            for (int64_t q = c; q <= last; ++q) pos[q] = W++;
+            c = last + 1;
+          }
+          if (W > maxW || W > 65535) { bad = true; break; }
+          pl.blkW[b] = W;
+          blk_nseg[b] = nseg;
+          // dictionary (<= 256 bit patterns) and the batch-major stream
+          std::fill(ids.begin(), ids.end(), (int16_t)-1);
+          const size_t d0 = t_dict[t].size();
+          uint8_t *sp = pl.stream.data() + pl.sb[b];
+          uint32_t eoff = 0;  // padded entry offset inside the block
+          auto code_of = [&](double value) -> int {   // dictionary code of a value (-1: more than 256 patterns)
+            uint64_t bits;
+            std::memcpy(&bits, &value, 8);
+            uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
+            for (;;) {
+              if (ids[h] < 0) {
+                if (t_dict[t].size() - d0 == 256) return -1;
+                keys[h] = bits;
+                ids[h] = (int16_t)(t_dict[t].size() - d0);
+                t_dict[t].push_back(value);
+                return ids[h];
+              }
+              if (keys[h] == bits) return ids[h];
+              h = (h + 1) & (kTab - 1);
+            }
+          };
+          for (size_t q = 0; q < bts.size() && !bad; ++q) {
+            const VsBatch &bt = bts[q];
+            const int NF = bt.cls > 0 ? bt.cls - 1 : 0;
+            const int64_t full = 64 * NF;
+            int64_t l = 0;
+            for (int i = 0; i < bt.nreal; ++i) l += len[bt.id[i]] - full;
+            const uint32_t T = (uint32_t)((l + 15) / 16 * 16);
+            uint8_t *fb = sp + 3 * (size_t)eoff;
+            uint16_t *lc = (uint16_t *)(fb + 768 * (size_t)NF);
+            uint8_t *vc = (uint8_t *)lc + 2 * (size_t)T;
+            uint64_t *dst = &pl.tab[((size_t)b * maxb + q) * 4];
+            uint32_t o = 0;
+            for (int i = 0; i < 4 && !bad; ++i) {
+              const int src = i < bt.nreal ? i : 0;     // fillers repeat the batch's first row
+              const int32_t r = rows[bt.id[src]];
+              const int64_t k0 = rp[r], n = len[bt.id[src]];
+              // full chunks: lane-major, the four row slots interleaved
+              for (int jf = 0; jf < NF && !bad; ++jf)
+                for (int ln = 0; ln < 64; ++ln) {
+                  const int64_t k = k0 + 64 * jf + ln;
+                  uint8_t *cell = fb + 768 * (size_t)jf + 12 * (size_t)ln;
+                  const int cd = code_of(val[k]);
+                  if (cd < 0) { bad = true; break; }
+                  const uint16_t w16 = (uint16_t)pos[col[k] - clo];
+                  std::memcpy(cell + 2 * i, &w16, 2);
+                  cell[8 + i] = (uint8_t)cd;
+                }
+              if (i >= bt.nreal) {
+                dst[i] = (dst[0] & 0xffffffffull) | (0xffffffffull << 32);
+                continue;
+              }
+              dst[i] = (uint64_t)(eoff + o) | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) |
+                       ((uint64_t)(uint32_t)r << 32);
+              for (int64_t k = full; k < n; ++k) {   // the last chunk, compact
+                const int cd = code_of(val[k0 + k]);
+                if (cd < 0) { bad = true; break; }
+                lc[o + (k - full)] = (uint16_t)pos[col[k0 + k] - clo];
+                vc[o + (k - full)] = (uint8_t)cd;
+              }
+              o += (uint32_t)(n - full);
+            }
+            eoff += (uint32_t)(4 * full) + T;
+          }
+          pl.dn[b] = (int32_t)(t_dict[t].size() - d0);
+        }
+      });
+    for (auto &x : th) x.join();
+  }
+  if (bad) return;
+  pl.seg_begin.assign(nb + 1, 0);
+  for (int64_t b = 0; b < nb; ++b) pl.seg_begin[b + 1] = pl.seg_begin[b] + blk_nseg[b];
+  pl.doff.reserve(nb);
+  for (int t = 0; t < T; ++t) {
+    const int32_t base = (int32_t)pl.dict.size();
+    for (int32_t o : t_doff[t]) pl.doff.push_back(base + o);
+    pl.dict.insert(pl.dict.end(), t_dict[t].begin(), t_dict[t].end());
+    pl.seg_col.insert(pl.seg_col.end(), t_seg_col[t].begin(), t_seg_col[t].end());
+    pl.seg_off.insert(pl.seg_off.end(), t_seg_off[t].begin(), t_seg_off[t].end());
+  }
+  if (pl.dict.size() > 2000000000ull) return;
+  int32_t mw = 1;
+  for (int64_t b = 0; b < nb; ++b) mw = std::max(mw, pl.blkW[b]);
+  pl.maxW = mw;
+  pl.ok = true;
+}
+
+static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const int32_t *col, const double *val) {
+  VsPlan pl;
+  const bool hint = slot >= 0 && slot <= ALFD_NSLOTS && !ctx->rb_ptr[slot].empty();
+  if (hint) {
+    // the hint must list every row exactly once
+    const auto &bp = ctx->rb_ptr[slot];
+    const auto &br = ctx->rb_rows[slot];
+    bool good = bp.front() == 0 && bp.back() == m.nrows && (int64_t)br.size() == m.nrows;
+    std::vector<uint8_t> seen(good ? m.nrows : 0, 0);
+    for (size_t i = 0; good && i < br.size(); ++i) {
+      good = br[i] >= 0 && br[i] < m.nrows && !seen[br[i]];
+      if (good) seen[br[i]] = 1;
+    }
+    for (size_t i = 0; good && i + 1 < bp.size(); ++i) good = bp[i] <= bp[i + 1];
+    if (!good) return ctx->err = "alfd_set_row_blocks: the blocks are not a partition of the matrix rows", ALFD_E_INVALID;
+    plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, (int64_t)bp.size() - 1, bp.data(),
+            br.data(), pl);
+  } else {
+    plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pl);
+  }
+  if (!pl.ok) return ALFD_OK;
+  DevCsr::Vs &v = m.vs;
+  RC(upload_vec(ctx, m, &v.stream, pl.stream));
+  RC(upload_vec(ctx, m, &v.sb, pl.sb));
+  RC(upload_vec(ctx, m, &v.tab, pl.tab));
+  RC(upload_vec(ctx, m, &v.cnt, pl.cnt));
+  RC(upload_vec(ctx, m, &v.seg_begin, pl.seg_begin));
+  RC(upload_vec(ctx, m, &v.blkW, pl.blkW));
+  RC(upload_vec(ctx, m, &v.seg_col, pl.seg_col));
+  RC(upload_vec(ctx, m, &v.seg_off, pl.seg_off));
+  RC(upload_vec(ctx, m, &v.doff, pl.doff));
+  RC(upload_vec(ctx, m, &v.dn, pl.dn));
+  RC(upload_vec(ctx, m, &v.dict, pl.dict));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  v.nb = pl.nb;
+  v.nseg = (int64_t)pl.seg_col.size();
+  v.stream_bytes = (int64_t)pl.stream.size() - 4096;
+  v.nbatch = pl.nbatch;
+  v.dict_total = (int64_t)pl.dict.size();
+  v.stride = pl.stride;
+  v.maxW = pl.maxW;
+  v.bricks = hint;
+  v.on = true;
+  if (ctx->cfg.log_level > 0)
+    std::fprintf(stderr, "[alfd] batch-major format: %lld blocks (%s), %lld batches, window <= %d slots, %.2f B/nnz\n",
+                 (long long)pl.nb, hint ? "caller's row blocks" : "runs of the numbering", (long long)pl.nbatch,
+                 pl.maxW, (double)v.stream_bytes / (double)std::max<int64_t>(m.nnz, 1));
+  return ALFD_OK;
+}
+
 static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, const int64_t *rp,
                          const int32_t *col, const double *val) {
   DevCsr &m = ctx->mat[slot];
@@ -1953,6 +2307,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
                          m.nrows >= (int64_t)std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / m.L) * 1024;
   if (ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0)
     RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot));
+  if (ctx->vs_enable && m.vi && m.L == 64 && slot != kScratchSlot) RC(build_vs(ctx, m, slot, rp, col_up, val));
   m.present = true;
   return ALFD_OK;
 }
@@ -3549,7 +3904,7 @@ int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value
   ctx->vi_off = !use_value_index;
   const int rc = alfd_bench_spmv(ctx, slot, reps, ms_per_launch, nullptr);
   ctx->vi_off = was_off;
-  if (streamed_bytes) *streamed_bytes = ctx->mat[slot].streamed_bytes(use_value_index != 0);
+  if (streamed_bytes) *streamed_bytes = ctx->mat[slot].streamed_bytes(use_value_index != 0, ctx->vs_enable != 0);
   return rc;
 }
 
@@ -3638,6 +3993,7 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   out->lanes = m.L;
   out->windowed = m.win ? 1 : 0;
   out->value_indexed = m.vi ? 1 : 0;
+  out->batch_major = (m.vs.on && ctx->vs_enable) ? (m.vs.bricks ? 2 : 1) : 0;
   out->nnz = m.nnz;
   out->window_blocks = m.win_nblocks;
   out->window_fallback_blocks = m.win_fallback_blocks;
@@ -3646,7 +4002,84 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   out->dictionary_entries = m.vi_dict_total;
   out->value_wide_nnz = m.vi_wide_nnz;
   out->algorithmic_bytes = m.algorithmic_bytes();
-  out->streamed_bytes = m.streamed_bytes(true);
+  out->streamed_bytes = m.streamed_bytes(true, ctx->vs_enable != 0);
+  return ALFD_OK;
+}
+
+int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int32_t row_block,
+                          int64_t n_blocks, const int64_t *block_ptr, const int32_t *rows,
+                          alfd_stream_plan_info *out) {
+  if (!rp || !out || nrows < 0 || row_block < 1 || row_block > kVsMaxRows) return ALFD_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  VsPlan pl;
+  if (n_blocks > 0) plan_vs(nrows, rp, col, val, row_block, 4096, 8, n_blocks, block_ptr, rows, pl);
+  else plan_vs(nrows, rp, col, val, row_block, 4096, 8, 0, nullptr, nullptr, pl);
+  out->ok = pl.ok ? 1 : 0;
+  if (!pl.ok) return ALFD_OK;
+  out->max_window = pl.maxW;
+  out->max_rows = pl.rbs;
+  out->max_batches = pl.stride;
+  out->blocks = pl.nb;
+  out->batches = pl.nbatch;
+  out->segments = (int64_t)pl.seg_col.size();
+  out->dictionary_entries = (int64_t)pl.dict.size();
+  out->stream_bytes = (int64_t)pl.stream.size() - 4096;
+  std::vector<uint8_t> seen(nrows, 0);
+  int64_t bad = 0, covered = 0;
+  std::vector<int32_t> slot_col;
+  for (int64_t b = 0; b < pl.nb; ++b) {
+    // window slot -> column
+    slot_col.assign(pl.blkW[b], -1);
+    for (int32_t s = pl.seg_begin[b]; s < pl.seg_begin[b + 1]; ++s) {
+      const int32_t end = s + 1 < pl.seg_begin[b + 1] ? pl.seg_off[s + 1] : pl.blkW[b];
+      for (int32_t o = pl.seg_off[s]; o < end; ++o) slot_col[o] = pl.seg_col[s] + (o - pl.seg_off[s]);
+    }
+    const int nbt = pl.cnt[b];
+    const uint8_t *sp = pl.stream.data() + pl.sb[b];
+    if (pl.sb[b] % 16) ++bad;
+    for (int q = 0; q < nbt; ++q) {
+      const uint64_t *dsc = &pl.tab[((size_t)b * pl.stride + q) * 4];
+      auto off = [](uint64_t dd) { return (uint32_t)dd & 0xfffffu; };
+      auto cnt_of = [](uint64_t dd) { return ((uint32_t)dd >> 20) & 0x1ffu; };
+      const uint32_t eb = off(dsc[0]);
+      if (eb % 16) ++bad;
+      const int cls = (int)(((uint32_t)dsc[0] >> 29) & 7u);
+      const int NF = cls > 0 ? cls - 1 : 0;
+      uint32_t end = 0;
+      for (int i = 0; i < 4; ++i) end = std::max(end, off(dsc[i]) - eb + cnt_of(dsc[i]) - 64u * NF);
+      const uint32_t T = (end + 15u) & ~15u;
+      const uint8_t *fb = sp + 3 * (size_t)eb;
+      const uint16_t *lc0 = (const uint16_t *)(fb + 768 * (size_t)NF);
+      const uint8_t *vc0 = (const uint8_t *)lc0 + 2 * (size_t)T;
+      for (int i = 0; i < 4; ++i) {
+        const int64_t r = (int32_t)(dsc[i] >> 32);
+        if (r < 0) continue;  // filler
+        if (r >= nrows || seen[r]) { ++bad; continue; }
+        seen[r] = 1;
+        ++covered;
+        const uint32_t o = off(dsc[i]) - eb, n = cnt_of(dsc[i]);
+        if ((int64_t)n != rp[r + 1] - rp[r] || (int)((n + 63) / 64) != cls) { ++bad; continue; }
+        for (uint32_t k = 0; k < n; ++k) {
+          uint32_t lcv, vcv;
+          if (k < 64u * NF) {
+            const uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64);
+            uint16_t w16;
+            std::memcpy(&w16, cell + 2 * i, 2);
+            lcv = w16;
+            vcv = cell[8 + i];
+          } else {
+            lcv = lc0[o + (k - 64u * NF)];
+            vcv = vc0[o + (k - 64u * NF)];
+          }
+          const double v = (int32_t)vcv < pl.dn[b] ? pl.dict[pl.doff[b] + vcv] : std::nan("");
+          const int32_t c = (int32_t)lcv < pl.blkW[b] ? slot_col[lcv] : -1;
+          if (c != col[rp[r] + k] || std::memcmp(&v, &val[rp[r] + k], 8) != 0) ++bad;
+        }
+      }
+    }
+  }
+  out->decode_mismatches = bad;
+  out->rows_covered = covered;
   return ALFD_OK;
 }
 
@@ -3665,7 +4098,35 @@ int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value) {
     ctx->vi_off = value == 0;
     return ALFD_OK;
   }
+  if (std::strcmp(name, "batch_major") == 0) {   // takes effect at the next alfd_set_matrix
+    ctx->vs_enable = value != 0;
+    return ALFD_OK;
+  }
+  if (std::strcmp(name, "batch_major_waves") == 0) {
+    if (value != 2 && value != 4 && value != 8) return ctx->err = "batch_major_waves: 2, 4 or 8", ALFD_E_INVALID;
+    ctx->vs_NW = value;
+    return ALFD_OK;
+  }
+  if (std::strcmp(name, "batch_major_rows") == 0) {
+    if (value < 4 || value > kVsMaxRows) return ctx->err = "batch_major_rows: 4..250", ALFD_E_INVALID;
+    ctx->vs_RB = value;
+    return ALFD_OK;
+  }
+  if (std::strcmp(name, "batch_major_xcd") == 0) {
+    ctx->vs_xcd = value != 0;
+    return ALFD_OK;
+  }
   return ctx->err = std::string("unknown tunable ") + name, ALFD_E_INVALID;
+}
+
+int alfd_set_row_blocks(alfd_ctx_t ctx, int slot, int64_t n_blocks, const int64_t *block_ptr, const int32_t *rows) {
+  if (!ctx || slot < 0 || slot >= ALFD_NSLOTS) return ALFD_E_INVALID;
+  ctx->rb_ptr[slot].clear();
+  ctx->rb_rows[slot].clear();
+  if (n_blocks <= 0 || !block_ptr || !rows) return ALFD_OK;   // hint removed
+  ctx->rb_ptr[slot].assign(block_ptr, block_ptr + n_blocks + 1);
+  ctx->rb_rows[slot].assign(rows, rows + block_ptr[n_blocks]);
+  return ALFD_OK;
 }
 
 int alfd_enable_timing(alfd_ctx_t ctx, int on) {

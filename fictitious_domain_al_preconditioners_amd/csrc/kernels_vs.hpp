@@ -1,0 +1,209 @@
+// Batch-major value-indexed SpMV ("vs" format) for gfx950.
+//
+// Same arithmetic as spmv_window_vib_kernel (canonical lane assignment, fma order and
+// 64-lane tree of ALFD-arith v1 -- bit-identical results); what differs is the storage:
+//
+//  * a row block is an arbitrary LIST of rows, not a run of the numbering.  With blocks that
+//    are bricks of the mesh graph (alfd_set_row_blocks) the x window a block stages in LDS is
+//    a third of that of 96 consecutive rows of a lexicographic numbering (825 instead of
+//    2 700 slots at 96 rows): less L2 -> LDS staging, less HBM re-fetch of x, and 8 resident
+//    waves per SIMD instead of 4.9 (the window no longer limits occupancy);
+//  * the 3 B/nnz stream (16-bit window column + 8-bit dictionary code) is stored BATCH-MAJOR:
+//    the rows of a block are grouped by chunk count into batches of 4.  A batch's FULL
+//    64-entry chunks are stored lane-major, the four rows interleaved (12 bytes per lane and
+//    chunk index: 4 window columns + 4 codes), so one global_load_dwordx3 replaces eight
+//    narrow loads; only the rows' last, partial chunks keep the compact (column, code) form.
+//    With the window small, the stream loads are what bounds the kernel (ablation: without
+//    them 0.61 ms, without the LDS gathers 1.29 of 1.30 ms), and a wave-level load costs the
+//    same ~8.5 issue cycles whether it carries 1 or 4 bytes per lane;
+//  * the 32-byte batch descriptor names the GLOBAL row of each of its 4 rows, so the four
+//    sums go straight to y.
+//
+// An LDS-DMA variant of this kernel (global_load_lds_dwordx4 into per-wave stream buffers,
+// ds_read_u16 / ds_read_u8 decode) was measured slower (1.78 vs 1.36 ms at N = 74): the
+// in-flight bytes HBM latency demands (~45 KB per CU) fit the register file, not the LDS
+// that also holds the windows -- profiles/r02/lds_dma_experiment/.
+#pragma once
+
+namespace alfd {
+
+constexpr int kVsDictOff = 0;     // 256 dictionary doubles at LDS offset 0
+constexpr int kVsWinOff = 2048;   // the x window behind them
+constexpr int kVsMaxRows = 250;   // rows per block
+constexpr int kVsMaxLen = 384;    // longest row the format takes (class 6)
+
+// batch descriptor, one uint64 per row: eb + t (20 bits) | entry count (9) | class = ceil(count / 64)
+// (3) | global row, 0xffffffff = filler (32).  eb: the batch's offset from the block's first
+// entry in padded entries (a multiple of 16; the batch starts at byte 3 eb), t: the offset of the
+// row's last chunk in the batch's tail.  Row 0 has t = 0; fillers repeat row 0.
+__device__ __forceinline__ uint32_t vs_off(uint64_t d) { return (uint32_t)d & 0xfffffu; }
+__device__ __forceinline__ int32_t vs_len(uint64_t d) { return (int32_t)(((uint32_t)d >> 20) & 0x1ffu); }
+__device__ __forceinline__ int vs_cls(uint64_t d) { return (int)(((uint32_t)d >> 29) & 7u); }
+
+struct VsWord3 {
+  uint32_t x, y, z;
+};
+
+// One batch of 4 rows with NCH chunks each.  fb: the batch's NCH-1 full chunks, lane-major -- for
+// chunk j, lane l holds at fb + 768 j + 12 l the window columns of rows 0..3 (4 x 16 bit) and their
+// codes (4 x 8 bit): ONE global_load_dwordx3 per chunk serves all four rows.  lc / vc: the rows'
+// last (partial) chunks, stored compactly; t[i] is row i's offset there, rem[i] its entry count.
+// All loads of the batch are issued before the first use.
+template <int NCH>
+__device__ __forceinline__ void vs_batch(const uint32_t (&t)[4], const int32_t (&rem)[4], int lane,
+                                         const uint8_t *__restrict__ fb, const uint16_t *__restrict__ lc,
+                                         const uint8_t *__restrict__ vc, const char *sm, double (&acc)[4]) {
+  constexpr int NF = NCH - 1;
+  VsWord3 w[NF > 0 ? NF : 1];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) w[j] = *(const VsWord3 *)(fb + 768 * j + 12 * lane);
+  int32_t c[4], iv[4];
+  bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ok[i] = lane < rem[i];
+    const uint32_t k = t[i] + (uint32_t)(ok[i] ? lane : 0);
+    c[i] = lc[k];
+    iv[i] = vc[k];
+  }
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    double xv[4], v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t cw = i < 2 ? w[j].x : w[j].y;
+      const uint32_t ci = (i & 1) ? (cw >> 16) : (cw & 0xffffu);
+      const uint32_t vi = (w[j].z >> (8 * i)) & 0xffu;
+      xv[i] = *(const double *)(sm + kVsWinOff + 8 * ci);
+      v[i] = *(const double *)(sm + kVsDictOff + 8 * vi);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[i]), "+v"(v[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = fma(v[i], xv[i], acc[i]);
+  }
+  {
+    double xv[4], v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xv[i] = *(const double *)(sm + kVsWinOff + 8 * c[i]);
+      v[i] = *(const double *)(sm + kVsDictOff + 8 * iv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[i]), "+v"(v[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (ok[i]) acc[i] = fma(v[i], xv[i], acc[i]);
+  }
+}
+
+template <int EPI, int TAG, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_vs_kernel(
+    const uint8_t *__restrict__ stream, const int64_t *__restrict__ sb, const uint64_t *__restrict__ tab,
+    const int32_t *__restrict__ cnt, int32_t stride, const int32_t *__restrict__ blk_seg_begin,
+    const int32_t *__restrict__ blk_W, const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
+    const int32_t *__restrict__ blk_dict_off, const int32_t *__restrict__ blk_dict_n,
+    const double *__restrict__ dict, const double *__restrict__ x, const double *__restrict__ x_halo,
+    int32_t n_local, double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2,
+    int xcd_remap) {
+  extern __shared__ double xs[];
+  char *sm = (char *)xs;
+  double *ds = (double *)(sm + kVsDictOff);
+  double *xw = (double *)(sm + kVsWinOff);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int64_t b = blockIdx.x;
+  if (xcd_remap) {  // workgroups with equal blockIdx % 8 share an XCD: give each XCD a contiguous run of blocks
+    const int64_t nwg = gridDim.x, q = nwg / 8, rm = nwg % 8, xcd = b % 8, idx = b / 8;
+    b = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + idx;
+  }
+  const int32_t nbatch = cnt[b];
+  const uint8_t *sbase = stream + sb[b];
+  const uint64_t *bt = tab + ((int64_t)b * stride + wave) * 4;
+  uint64_t nx[4] = {0, 0, 0, 0};
+  if (wave < nbatch) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nx[i] = bt[i];
+  }
+  {  // block frame: dictionary and x window (segments of at most 64 slots, 4 in flight per wave)
+    const int32_t nd = blk_dict_n[b];
+    for (int t = threadIdx.x; t < nd; t += 64 * NW) ds[t] = dict[blk_dict_off[b] + t];
+    const int32_t W = blk_W[b];
+    const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
+    constexpr int U = 4;
+    for (int32_t s = s0 + wave * U; s < s1; s += NW * U) {
+      int32_t c0[U], o0[U], sl[U];
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t q = s + u < s1 ? s + u : s1 - 1;   // wave-uniform; the tail repeats the last segment
+        c0[u] = seg_col[q];
+        o0[u] = seg_off[q];
+        sl[u] = ((q + 1 < s1) ? seg_off[q + 1] : W) - o0[u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t c = c0[u] + (lane < sl[u] ? lane : 0);
+        v[u] = (c < n_local) ? x[c] : x_halo[c - n_local];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (lane < sl[u]) xw[o0[u] + lane] = v[u];
+    }
+  }
+  __syncthreads();
+  for (int32_t bi = wave; bi < nbatch; bi += NW) {
+    uint64_t desc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) desc[i] = nx[i];
+    bt += 4 * NW;
+    if (bi + NW < nbatch) {  // next descriptor: one s_load_dwordx8, in flight during this batch
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nx[i] = bt[i];
+    }
+    const uint32_t eb = vs_off(desc[0]);
+    const int cls = vs_cls(desc[0]);
+    const int32_t full = cls > 0 ? 64 * (cls - 1) : 0;
+    uint32_t end = 0, t[4];
+    int32_t rem[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      t[i] = vs_off(desc[i]) - eb;
+      rem[i] = vs_len(desc[i]) - full;
+      const uint32_t e = t[i] + (uint32_t)rem[i];
+      end = e > end ? e : end;
+    }
+    const uint32_t T = (end + 15u) & ~15u;
+    const uint8_t *fb = sbase + 3u * (size_t)eb;
+    const uint16_t *lc = (const uint16_t *)(fb + 768u * (uint32_t)(cls > 0 ? cls - 1 : 0));
+    const uint8_t *vc = (const uint8_t *)lc + 2u * (size_t)T;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    switch (cls) {
+      case 1: vs_batch<1>(t, rem, lane, fb, lc, vc, sm, acc); break;
+      case 2: vs_batch<2>(t, rem, lane, fb, lc, vc, sm, acc); break;
+      case 3: vs_batch<3>(t, rem, lane, fb, lc, vc, sm, acc); break;
+      case 4: vs_batch<4>(t, rem, lane, fb, lc, vc, sm, acc); break;
+      case 5: vs_batch<5>(t, rem, lane, fb, lc, vc, sm, acc); break;
+      case 6: vs_batch<6>(t, rem, lane, fb, lc, vc, sm, acc); break;
+      default: break;  // class 0: empty rows
+    }
+    const double s = reduce_rows4(acc[0], acc[1], acc[2], acc[3]);
+    const int q = lane >> 4;  // 16-lane row q holds the tree of batch row {0, 2, 1, 3}[q]
+    const uint64_t dq = q == 0 ? desc[0] : (q == 1 ? desc[2] : (q == 2 ? desc[1] : desc[3]));
+    const int32_t r = (int32_t)(dq >> 32);
+    if ((lane & 15) == 0 && r >= 0) {
+      if (EPI == 0)
+        y[r] = s;
+      else if (EPI == 1)
+        y[r] = fma(alpha, s, y[r]);
+      else if (EPI == 2)
+        y[r] = d[r] * s;
+      else {
+        y[r] = s;
+        y2[r] = d[r] * s;
+      }
+    }
+  }
+}
+
+}  // namespace alfd

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "alfd_set_aggregate_partition", "alfd_get_matrix_info", "alfd_bench_spmv_format",
     "alfd_host_window_plan", "alfd_set_tunable", "alfd_build_aggregates", "alfd_get_aggregates",
     "alfd_host_aggregate_level", "alfd_comm_init_host",
-    "alfd_get_device_memory",
+    "alfd_get_device_memory", "alfd_set_row_blocks", "alfd_host_stream_plan",
 ]
 
 
@@ -102,6 +102,8 @@ def load_library():
         "alfd_host_aggregate_level": (C.c_int, [i64, vp, vp, vp, i32, dbl, i32, vp, C.POINTER(i64)]),
         "alfd_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
         "alfd_get_device_memory": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
+        "alfd_set_row_blocks": (C.c_int, [vp, C.c_int, i64, vp, vp]),
+        "alfd_host_stream_plan": (C.c_int, [i64, vp, vp, vp, C.c_int32, i64, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -318,6 +320,15 @@ class Context:
         """Run-time switch (alfd_set_tunable), e.g. ("value_index", 0): general-matrix SpMV kernel."""
         self._ck(self._lib.alfd_set_tunable(self._h, name.encode(), int(value)))
 
+    def set_row_blocks(self, slot, block_ptr, rows):
+        """Row-block hint of the batch-major SpMV format (alfd_set_row_blocks); None removes it."""
+        if block_ptr is None:
+            self._ck(self._lib.alfd_set_row_blocks(self._h, slot, 0, None, None))
+            return
+        bp = np.ascontiguousarray(block_ptr, np.int64)
+        rw = np.ascontiguousarray(rows, np.int32)
+        self._ck(self._lib.alfd_set_row_blocks(self._h, slot, bp.size - 1, bp.ctypes.data, rw.ctypes.data))
+
     def device_memory(self):
         """(free, total) bytes of the context's GPU."""
         f, t = C.c_int64(0), C.c_int64(0)
@@ -398,6 +409,27 @@ def host_window_plan(m, lanes=64, value_index=True):
                                    int(value_index), C.byref(info))
     if rc != _abi.OK:
         raise AlfdError(rc, "alfd_host_window_plan failed")
+    return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+def host_stream_plan(m, row_block=96, blocks=None):
+    """Host-only plan + decode of the batch-major format (alfd_host_stream_plan);
+    blocks = (block_ptr, rows) as for Context.set_row_blocks, or None for runs of row_block rows."""
+    lib = load_library()
+    rp = np.ascontiguousarray(m.row_ptr, np.int64)
+    col = np.ascontiguousarray(m.col, np.int32)
+    val = np.ascontiguousarray(m.val, np.float64)
+    info = _abi.StreamPlanInfo()
+    if blocks is None:
+        rc = lib.alfd_host_stream_plan(m.nrows, rp.ctypes.data, col.ctypes.data, val.ctypes.data, row_block,
+                                       0, None, None, C.byref(info))
+    else:
+        bp = np.ascontiguousarray(blocks[0], np.int64)
+        rw = np.ascontiguousarray(blocks[1], np.int32)
+        rc = lib.alfd_host_stream_plan(m.nrows, rp.ctypes.data, col.ctypes.data, val.ctypes.data, row_block,
+                                       bp.size - 1, bp.ctypes.data, rw.ctypes.data, C.byref(info))
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_stream_plan failed")
     return {k: getattr(info, k) for k, _ in info._fields_}
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 9
+#define ALFD_ABI_VERSION 10
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -363,7 +363,8 @@ int alfd_bench_spmv(alfd_ctx_t ctx, int slot, int32_t reps, double *ms_per_launc
  * dictionary-coded values.  streamed_bytes is what one SpMV launch of the kernel
  * in use moves by format; algorithmic_bytes is the plain-CSR figure of SURVEY 8(d). */
 typedef struct alfd_matrix_info {
-  int32_t lanes, windowed, value_indexed, reserved;
+  int32_t lanes, windowed, value_indexed;
+  int32_t batch_major;   /* 0: no; 1: batch-major format on runs of the numbering; 2: on the caller's row blocks */
   int64_t nnz, window_blocks, window_fallback_blocks;
   int64_t value_indexed_blocks, value_indexed_nnz, dictionary_entries, value_wide_nnz;
   double algorithmic_bytes, streamed_bytes;
@@ -383,10 +384,31 @@ typedef struct alfd_window_plan_info {
 } alfd_window_plan_info;
 int alfd_host_window_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
                           int32_t lanes, int32_t want_value_index, alfd_window_plan_info *out);
+/* Host-only: plans the batch-major format (tunable "batch_major") of a CSR matrix as
+ * alfd_set_matrix would -- row blocks = runs of `row_block` rows, or the caller's blocks as in
+ * alfd_set_row_blocks when n_blocks > 0 -- and decodes it back (rows through the batch
+ * descriptors, columns through the window segments, values through the dictionaries). */
+typedef struct alfd_stream_plan_info {
+  int32_t ok, max_window, max_rows, max_batches;
+  int64_t blocks, batches, segments, dictionary_entries, stream_bytes;
+  int64_t decode_mismatches, rows_covered;
+} alfd_stream_plan_info;
+int alfd_host_stream_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                          int32_t row_block, int64_t n_blocks, const int64_t *block_ptr, const int32_t *rows,
+                          alfd_stream_plan_info *out);
 /* alfd_bench_spmv with the value-indexed kernel switched on (1) or off (0: the same
  * matrix through the 10 B/nnz window kernel); streamed_bytes as in alfd_matrix_info. */
 int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value_index,
                            double *ms_per_launch, double *streamed_bytes);
+/* Row-block hint for the batch-major SpMV format of a long-row matrix (tunable "batch_major" = 1):
+ * a partition of the rows of `slot` into blocks of at most 250 rows -- rows[block_ptr[b] .. block_ptr[b+1])
+ * -- whose columns are close together, e.g. bricks of the mesh (all components of the nodes of a
+ * 4 x 4 x 4 patch).  A block stages ONE window of x in LDS, so the fewer distinct columns a block
+ * touches the better; the result of the SpMV does not depend on the blocks (each row keeps the
+ * canonical summation order).  Takes effect at the next alfd_set_matrix of that slot; n_blocks = 0
+ * removes the hint (blocks are then runs of the row numbering). */
+int alfd_set_row_blocks(alfd_ctx_t ctx, int slot, int64_t n_blocks, const int64_t *block_ptr, const int32_t *rows);
+
 /* Free / total bytes of the context's device (hipMemGetInfo): leak checks, capacity planning. */
 int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_bytes);
 /* Run-time switches of a context (measurement and A/B comparison; results never change):

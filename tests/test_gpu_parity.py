@@ -53,6 +53,46 @@ def test_spmv_bitwise(ctxs, name, mode):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("blocks", ["runs", "bricks", "bricks444", "ragged"])
+def test_batch_major_format_bitwise(built, blocks):
+    """The batch-major value-indexed format (kernels_vs.hpp, tunable batch_major): row blocks as runs of
+    the numbering, as mesh bricks handed in through alfd_set_row_blocks, and as ragged random-size
+    blocks of a random row permutation; every epilogue; against the oracle's canonical SpMV."""
+    big = problems.generate(dim=3, degree=2, ncomp=3, n_cells=20, stokes=False, grad_div=True,
+                            gamma_grad_div=10.0, radius=0.1, immersed_refine=0)
+    m = big.mats["A"]
+    rng = np.random.default_rng(11)
+    ctx = solver.Context(0)
+    try:
+        ctx.set_tunable("batch_major", 1)
+        if blocks == "bricks":
+            ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(big.params, (8, 2, 2)))
+        elif blocks == "bricks444":
+            ctx.set_tunable("batch_major_waves", 8)
+            ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(big.params, (4, 4, 4)))
+        elif blocks == "ragged":
+            perm = np.argsort((np.arange(m.nrows) // 32) * 1000 + rng.integers(0, 1000, m.nrows), kind="stable")
+            sizes = rng.integers(1, 48, m.nrows // 16)
+            ptr = np.minimum(np.r_[0, np.cumsum(sizes)], m.nrows)
+            ptr = np.unique(np.r_[ptr, m.nrows])
+            ctx.set_row_blocks(_abi.A, ptr, perm)
+        ctx.set_matrix(_abi.A, m)
+        info = ctx.matrix_info(_abi.A)
+        assert info["batch_major"] == (1 if blocks == "runs" else 2), info
+        assert info["streamed_bytes"] < (4.0 if blocks == "ragged" else 3.4) * m.nnz
+        x = _rng_vec(m.ncols, 3)
+        y0 = _rng_vec(m.nrows, 4)
+        for mode in (0, 1):
+            got, lanes = ctx.spmv(_abi.A, x, y0, mode=mode, alpha=-0.75)
+            ref, olanes = oracle.spmv(m, x, y0 if mode else None, mode=mode, alpha=-0.75)
+            assert lanes == olanes and np.array_equal(got, ref), (blocks, mode)
+        with pytest.raises(solver.AlfdError):
+            ctx.set_row_blocks(_abi.A, np.array([0, 5, m.nrows]), np.zeros(m.nrows, np.int32))   # not a partition
+            ctx.set_matrix(_abi.A, m)
+    finally:
+        ctx.close()
+
+
 def test_spmv_every_kernel_family_bitwise(built):
     """Matrices that exercise each lanes-per-row kernel, the sparse-row form, the
     streaming kernel and the LDS-windowed kernel (>= 2048 row blocks), incl.
