@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--cheb-degree", type=int, default=4)
     ap.add_argument("--inner-max", type=int, default=100,
                     help="cap of the inner CG: 100 = parameters_stokes_3d.prm:23 (the reference throws beyond it)")
+    ap.add_argument("--bricks", default="8,4,2",
+                    help="row blocks of the A-SpMV: nodes of an a x b x c patch of the velocity grid (0 = runs of the numbering)")
     ap.add_argument("--general-steps", type=int, default=1,
                     help="extra timed solves with the dictionary-free 10 B/nnz SpMV kernel (0 = skip)")
     ap.add_argument("--inner-prec", choices=["chebyshev", "multilevel"],
@@ -119,6 +121,12 @@ def main():
         levels = partition.partitioned_geometric_aggregates(pb.params, plan, a=args.agg_a, min_coarse=args.min_coarse)   # slab-respecting boxes
         aggregates = partition.local_aggregates(levels, rank)
         log(f"aggregates: levels {[lv[1] for lv in levels]} in {time.time()-ta:.1f} s")
+    if args.bricks != "0":
+        # row blocks of the A-SpMV = bricks of the Q2 grid inside this rank's slab (alfd_set_row_blocks):
+        # a third of the x window that 96 consecutive rows of the lexicographic numbering need
+        brick = tuple(int(v) for v in args.bricks.split(","))
+        ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(
+            pb.params, brick, node_range=(int(plan.node_offsets_u[rank]), int(plan.node_offsets_u[rank + 1]))))
     solver.upload_problem(ctx, pb, cfg, aggregates)
     rhs = ctx.augment_rhs([pb.vecs["f"], pb.vecs["rhs_p"], pb.vecs["g"]])
     ctx.upload_rhs(rhs)
@@ -170,7 +178,8 @@ def main():
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            if t.get("n_cells") == n and world == 1 and bool(t.get("value_indexed")) == bool(info["value_indexed"]):
+            if (t.get("n_cells") == n and world == 1 and bool(t.get("value_indexed")) == bool(info["value_indexed"])
+                    and int(t.get("batch_major", 0)) == int(info["batch_major"])):
                 traffic = t.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -230,7 +239,10 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("spmv_window_vib_kernel<0,0,4> (A, LDS-windowed CSR, dictionary-coded values, class-batched rows)"
+            "kernel": ("spmv_vs_kernel<0,0,4> (A, batch-major dictionary-coded stream, "
+                       + ("mesh-brick row blocks " + args.bricks.replace(",", "x") if info["batch_major"] == 2 else "row runs") + ")"
+                       if info["batch_major"] else
+                       "spmv_window_vib_kernel<0,0,4> (A, LDS-windowed CSR, dictionary-coded values, class-batched rows)"
                        if info["value_indexed"] else "spmv_window_kernel<2,8,0,0> (A, LDS-windowed CSR)"),
             # achieved = bytes one launch has to move in the storage format the kernel reads (DESIGN.md
             # section 5: what a perfect cache would still fetch) / HIP-event launch time; frac <= 1 by

@@ -271,7 +271,7 @@ struct alfd_ctx {
   int win_RB_vi = 96;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
   int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
-  int vs_enable = 0, vs_NW = 4, vs_RB = 96, vs_xcd = 0;   // batch-major format (alfd_set_tunable "batch_major")
+  int vs_enable = 1, vs_NW = 4, vs_RB = 96, vs_xcd = 0;   // batch-major format (alfd_set_tunable "batch_major")
   std::vector<int64_t> rb_ptr[ALFD_NSLOTS + 1];   // row-block hint per slot (alfd_set_row_blocks)
   std::vector<int32_t> rb_rows[ALFD_NSLOTS + 1];
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
@@ -633,10 +633,18 @@ static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y
   const DevCsr::Vs &v = m.vs;
   const int NW = ctx->vs_NW;
   const size_t lds = (size_t)kVsWinOff + (size_t)v.maxW * sizeof(double);
-#define ALFD_VS(EPI, NWV)                                                                                       \
-  hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, NWV>), dim3((unsigned)v.nb), dim3(64 * NWV), lds, ctx->stream,   \
-                     v.stream, v.sb, v.tab, v.cnt, v.stride, v.seg_begin, v.blkW, v.seg_col, v.seg_off, v.doff, \
-                     v.dn, v.dict, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->vs_xcd)
+#define ALFD_VS_ARGS                                                                                          \
+  v.stream, v.sb, v.tab, v.cnt, v.stride, v.seg_begin, v.blkW, v.seg_col, v.seg_off, v.doff, v.dn, v.dict, x, \
+      m.halo, m.n_local_cols, y, alpha, d, y2, ctx->vs_xcd
+#define ALFD_VS(EPI, NWV)                                                                                        \
+  do {                                                                                                           \
+    if (m.tag == 0)                                                                                              \
+      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, NWV>), dim3((unsigned)v.nb), dim3(64 * NWV), lds, ctx->stream, \
+                         ALFD_VS_ARGS);                                                                          \
+    else /* multigrid level matrix: its own instantiation, so that profiles keep the two apart */               \
+      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 1, 4>), dim3((unsigned)v.nb), dim3(256), lds, ctx->stream,        \
+                         ALFD_VS_ARGS);                                                                          \
+  } while (0)
 #define ALFD_VS_E(NWV)                  \
   do {                                  \
     if (epi == 0) ALFD_VS(0, NWV);      \
@@ -649,6 +657,7 @@ static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y
   else ALFD_VS_E(4);
 #undef ALFD_VS_E
 #undef ALFD_VS
+#undef ALFD_VS_ARGS
   return true;
 }
 
@@ -1903,36 +1912,115 @@ struct VsBatch {
 // class-sorted batches of one block (rows given by their block-local ids 0..nr-1 and lengths)
 static bool vs_batches(int nr, const int64_t *len, std::vector<VsBatch> &out) {
   out.clear();
+  for (int i = 0; i < nr; ++i)
+    if (len[i] > kVsMaxLen) return false;
+  std::vector<int> ids;
   for (int cls = 0; cls <= 6; ++cls) {
-    const int R = 4;
-    VsBatch bt{cls, 0, {0, 0, 0, 0}};
-    for (int i = 0; i < nr; ++i) {
-      if (len[i] > kVsMaxLen) return false;
-      if ((int)((len[i] + 63) / 64) != cls) continue;
-      bt.id[bt.nreal++] = i;
-      if (bt.nreal == R) {
-        out.push_back(bt);
-        bt.nreal = 0;
-      }
+    ids.clear();
+    for (int i = 0; i < nr; ++i)
+      if ((int)((len[i] + 63) / 64) == cls) ids.push_back(i);
+    // longest first: the rows of a batch then have equal or close remainders in the last chunk
+    std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return len[a] > len[b]; });
+    for (size_t q = 0; q < ids.size(); q += 4) {
+      VsBatch bt{cls, 0, {0, 0, 0, 0}};
+      for (size_t i = q; i < std::min(q + 4, ids.size()); ++i) bt.id[bt.nreal++] = ids[i];
+      out.push_back(bt);
     }
-    if (bt.nreal) out.push_back(bt);
   }
   return true;
 }
 
-static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int RB, int maxW,
-                    int GAP, int64_t nb_in, const int64_t *bptr, const int32_t *brows, VsPlan &pl) {
+// 3-byte units a batch occupies: 4 row slots x (full chunks + the longest remainder, rounded up to 4 lanes)
+static int64_t vs_batch_units(const VsBatch &q, const int64_t *len) {
+  if (q.cls == 0) return 0;
+  const int64_t full = 64 * (q.cls - 1);
+  int64_t mr = 1;
+  for (int i = 0; i < q.nreal; ++i) mr = std::max(mr, len[q.id[i]] - full);
+  return 4 * (full + (mr + 3) / 4 * 4);
+}
+
+// Blocks whose entries take more than kVsMaxDict distinct values (9-bit codes), or that list more than
+// kVsMaxRows rows, are halved until they fit; false if a single row does not fit.
+static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val, int RB, int64_t nb_in,
+                             const int64_t *bptr, const int32_t *brows, std::vector<int64_t> &optr,
+                             std::vector<int32_t> &orows) {
   const bool nat = bptr == nullptr;
   const int64_t nb = nat ? (nrows + RB - 1) / RB : nb_in;
+  const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::vector<int64_t>> t_sizes(T);
+  std::atomic<bool> bad(false);
+  orows.resize(nrows);
+  if (nat) {
+    for (int64_t r = 0; r < nrows; ++r) orows[r] = (int32_t)r;
+  } else {
+    std::copy(brows, brows + nrows, orows.begin());
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() {
+      constexpr int kTab = 1024;   // open addressing over the 64-bit patterns; stamps avoid clearing
+      std::vector<uint64_t> keys(kTab);
+      std::vector<uint32_t> stamp(kTab, 0);
+      uint32_t gen = 0;
+      std::vector<std::pair<int64_t, int64_t>> stack;
+      for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
+        const int64_t lo = nat ? b * RB : bptr[b], hi = nat ? std::min<int64_t>((b + 1) * RB, nrows) : bptr[b + 1];
+        stack.clear();
+        stack.emplace_back(lo, hi);
+        while (!stack.empty() && !bad) {   // depth-first, left half first: pieces come out in row-list order
+          const auto [a, e] = stack.back();
+          stack.pop_back();
+          bool fits = e - a <= kVsMaxRows;
+          if (fits) {
+            ++gen;
+            int distinct = 0;
+            for (int64_t i = a; i < e && fits; ++i) {
+              const int32_t r = orows[i];
+              for (int64_t k = rp[r]; k < rp[r + 1] && fits; ++k) {
+                uint64_t bits;
+                std::memcpy(&bits, &val[k], 8);
+                uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
+                while (stamp[h] == gen && keys[h] != bits) h = (h + 1) & (kTab - 1);
+                if (stamp[h] != gen) {
+                  stamp[h] = gen;
+                  keys[h] = bits;
+                  fits = ++distinct <= kVsMaxDict;
+                }
+              }
+            }
+          }
+          if (fits) {
+            t_sizes[t].push_back(e - a);
+          } else if (e - a <= 1) {
+            bad = true;
+          } else {
+            const int64_t mid = a + (e - a) / 2;
+            stack.emplace_back(mid, e);
+            stack.emplace_back(a, mid);
+          }
+        }
+      }
+    });
+  for (auto &x : th) x.join();
+  if (bad) return false;
+  optr.assign(1, 0);
+  for (int t = 0; t < T; ++t)
+    for (int64_t sz : t_sizes[t]) optr.push_back(optr.back() + sz);
+  // blocks that had to be cut to a quarter of their size on average: the values do not repeat
+  // enough for this format (a window per handful of rows costs more than the codes save)
+  return (int64_t)optr.size() - 1 <= 4 * nb + 16;
+}
+
+static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int RB, int maxW,
+                    int GAP, int64_t nb_in, const int64_t *bptr_in, const int32_t *brows_in, VsPlan &pl) {
+  std::vector<int64_t> r_ptr;
+  std::vector<int32_t> r_rows;
+  if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, nb_in, bptr_in, brows_in, r_ptr, r_rows)) return;
+  const int64_t *bptr = r_ptr.data();
+  const int32_t *brows = r_rows.data();
+  const int64_t nb = (int64_t)r_ptr.size() - 1;
   if (nb == 0 || nb > 2147483000LL) return;
-  auto blk_rows = [&](int64_t b, std::vector<int32_t> &rows) {
-    rows.clear();
-    if (nat) {
-      for (int64_t r = b * RB; r < std::min<int64_t>((b + 1) * RB, nrows); ++r) rows.push_back((int32_t)r);
-    } else {
-      rows.assign(brows + bptr[b], brows + bptr[b + 1]);
-    }
-  };
+  auto blk_rows = [&](int64_t b, std::vector<int32_t> &rows) { rows.assign(brows + bptr[b], brows + bptr[b + 1]); };
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   // pass 1: batch counts and stream extents
   std::vector<int64_t> blk_entries(nb, 0);
@@ -1952,12 +2040,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
           for (size_t i = 0; i < rows.size(); ++i) len[i] = rp[rows[i] + 1] - rp[rows[i]];
           if (!vs_batches((int)rows.size(), len.data(), bts)) { bad = true; break; }
           int64_t e = 0;
-          for (const VsBatch &q : bts) {
-            const int64_t full = q.cls > 0 ? 64 * (q.cls - 1) : 0;
-            int64_t l = 0;
-            for (int i = 0; i < q.nreal; ++i) l += len[q.id[i]] - full;
-            e += 4 * full + (l + 15) / 16 * 16;   // lane-major full chunks of 4 row slots + compact tail
-          }
+          for (const VsBatch &q : bts) e += vs_batch_units(q, len.data());
           blk_entries[b] = e;
           blk_nbatch[b] = (int32_t)bts.size();
           blk_nrows[b] = (int32_t)rows.size();
@@ -2043,21 +2126,21 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
             for (int64_t q = c; q <= last; ++q) pos[q] = W++;
             c = last + 1;
           }
-          if (W > maxW || W > 65535) { bad = true; break; }
+          if (W > maxW || W > 4096) { bad = true; break; }
           pl.blkW[b] = W;
           blk_nseg[b] = nseg;
-          // dictionary (<= 256 bit patterns) and the batch-major stream
+          // dictionary (<= kVsMaxDict bit patterns) and the batch-major stream
           std::fill(ids.begin(), ids.end(), (int16_t)-1);
           const size_t d0 = t_dict[t].size();
           uint8_t *sp = pl.stream.data() + pl.sb[b];
           uint32_t eoff = 0;  // padded entry offset inside the block
-          auto code_of = [&](double value) -> int {   // dictionary code of a value (-1: more than 256 patterns)
+          auto code_of = [&](double value) -> int {   // dictionary code of a value (-1: too many patterns)
             uint64_t bits;
             std::memcpy(&bits, &value, 8);
             uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
             for (;;) {
               if (ids[h] < 0) {
-                if (t_dict[t].size() - d0 == 256) return -1;
+                if (t_dict[t].size() - d0 == (size_t)kVsMaxDict) return -1;
                 keys[h] = bits;
                 ids[h] = (int16_t)(t_dict[t].size() - d0);
                 t_dict[t].push_back(value);
@@ -2069,46 +2152,25 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
           };
           for (size_t q = 0; q < bts.size() && !bad; ++q) {
             const VsBatch &bt = bts[q];
-            const int NF = bt.cls > 0 ? bt.cls - 1 : 0;
-            const int64_t full = 64 * NF;
-            int64_t l = 0;
-            for (int i = 0; i < bt.nreal; ++i) l += len[bt.id[i]] - full;
-            const uint32_t T = (uint32_t)((l + 15) / 16 * 16);
             uint8_t *fb = sp + 3 * (size_t)eoff;
-            uint16_t *lc = (uint16_t *)(fb + 768 * (size_t)NF);
-            uint8_t *vc = (uint8_t *)lc + 2 * (size_t)T;
             uint64_t *dst = &pl.tab[((size_t)b * maxb + q) * 4];
-            uint32_t o = 0;
             for (int i = 0; i < 4 && !bad; ++i) {
               const int src = i < bt.nreal ? i : 0;     // fillers repeat the batch's first row
               const int32_t r = rows[bt.id[src]];
               const int64_t k0 = rp[r], n = len[bt.id[src]];
-              // full chunks: lane-major, the four row slots interleaved
-              for (int jf = 0; jf < NF && !bad; ++jf)
-                for (int ln = 0; ln < 64; ++ln) {
-                  const int64_t k = k0 + 64 * jf + ln;
-                  uint8_t *cell = fb + 768 * (size_t)jf + 12 * (size_t)ln;
-                  const int cd = code_of(val[k]);
-                  if (cd < 0) { bad = true; break; }
-                  const uint16_t w16 = (uint16_t)pos[col[k] - clo];
-                  std::memcpy(cell + 2 * i, &w16, 2);
-                  cell[8 + i] = (uint8_t)cd;
-                }
-              if (i >= bt.nreal) {
-                dst[i] = (dst[0] & 0xffffffffull) | (0xffffffffull << 32);
-                continue;
-              }
-              dst[i] = (uint64_t)(eoff + o) | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) |
-                       ((uint64_t)(uint32_t)r << 32);
-              for (int64_t k = full; k < n; ++k) {   // the last chunk, compact
+              for (int64_t k = 0; k < n; ++k) {   // entry k: chunk k / 64, lane k % 64, row slot i
+                uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64);
                 const int cd = code_of(val[k0 + k]);
                 if (cd < 0) { bad = true; break; }
-                lc[o + (k - full)] = (uint16_t)pos[col[k0 + k] - clo];
-                vc[o + (k - full)] = (uint8_t)cd;
+                const uint32_t f = ((uint32_t)cd << 15) | ((uint32_t)pos[col[k0 + k] - clo] << 3);
+                cell[3 * i] = (uint8_t)f;   // row slot i: bytes 3i .. 3i+2 of the 12-byte cell
+                cell[3 * i + 1] = (uint8_t)(f >> 8);
+                cell[3 * i + 2] = (uint8_t)(f >> 16);
               }
-              o += (uint32_t)(n - full);
+              dst[i] = (uint64_t)eoff | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) |
+                       ((uint64_t)(i < bt.nreal ? (uint32_t)r : 0xffffffffu) << 32);
             }
-            eoff += (uint32_t)(4 * full) + T;
+            eoff += (uint32_t)vs_batch_units(bt, len.data());
           }
           pl.dn[b] = (int32_t)(t_dict[t].size() - d0);
         }
@@ -2135,7 +2197,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
 
 static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const int32_t *col, const double *val) {
   VsPlan pl;
-  const bool hint = slot >= 0 && slot <= ALFD_NSLOTS && !ctx->rb_ptr[slot].empty();
+  const bool hint = slot >= 0 && slot < ALFD_NSLOTS && !ctx->rb_ptr[slot].empty();
   if (hint) {
     // the hint must list every row exactly once
     const auto &bp = ctx->rb_ptr[slot];
@@ -2307,7 +2369,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
                          m.nrows >= (int64_t)std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / m.L) * 1024;
   if (ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0)
     RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot));
-  if (ctx->vs_enable && m.vi && m.L == 64 && slot != kScratchSlot) RC(build_vs(ctx, m, slot, rp, col_up, val));
+  if (ctx->vs_enable && m.vi && m.L == 64) RC(build_vs(ctx, m, slot, rp, col_up, val));
   m.present = true;
   return ALFD_OK;
 }
@@ -3400,6 +3462,7 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
   if (const char *e = std::getenv("ALFD_ML_REPLICATE")) ctx->ml_rep_threshold = std::atoll(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_LEVELS")) ctx->vi_levels = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_BATCH_MAJOR")) ctx->vs_enable = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_XCD")) ctx->vi_xcd = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_BATCHED")) ctx->vi_batched = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB_VI")) ctx->win_RB_vi = std::atoi(e);
@@ -4044,33 +4107,20 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
       const uint32_t eb = off(dsc[0]);
       if (eb % 16) ++bad;
       const int cls = (int)(((uint32_t)dsc[0] >> 29) & 7u);
-      const int NF = cls > 0 ? cls - 1 : 0;
-      uint32_t end = 0;
-      for (int i = 0; i < 4; ++i) end = std::max(end, off(dsc[i]) - eb + cnt_of(dsc[i]) - 64u * NF);
-      const uint32_t T = (end + 15u) & ~15u;
       const uint8_t *fb = sp + 3 * (size_t)eb;
-      const uint16_t *lc0 = (const uint16_t *)(fb + 768 * (size_t)NF);
-      const uint8_t *vc0 = (const uint8_t *)lc0 + 2 * (size_t)T;
       for (int i = 0; i < 4; ++i) {
         const int64_t r = (int32_t)(dsc[i] >> 32);
         if (r < 0) continue;  // filler
         if (r >= nrows || seen[r]) { ++bad; continue; }
         seen[r] = 1;
         ++covered;
-        const uint32_t o = off(dsc[i]) - eb, n = cnt_of(dsc[i]);
-        if ((int64_t)n != rp[r + 1] - rp[r] || (int)((n + 63) / 64) != cls) { ++bad; continue; }
+        const uint32_t n = cnt_of(dsc[i]);
+        if (off(dsc[i]) != eb || (int64_t)n != rp[r + 1] - rp[r] || (int)((n + 63) / 64) != cls) { ++bad; continue; }
         for (uint32_t k = 0; k < n; ++k) {
-          uint32_t lcv, vcv;
-          if (k < 64u * NF) {
-            const uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64);
-            uint16_t w16;
-            std::memcpy(&w16, cell + 2 * i, 2);
-            lcv = w16;
-            vcv = cell[8 + i];
-          } else {
-            lcv = lc0[o + (k - 64u * NF)];
-            vcv = vc0[o + (k - 64u * NF)];
-          }
+          const uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64);
+          const uint32_t f = cell[3 * i] | ((uint32_t)cell[3 * i + 1] << 8) | ((uint32_t)cell[3 * i + 2] << 16);
+          const uint32_t lcv = (f >> 3) & 0xfffu, vcv = f >> 15;
+          if (f & 7u) ++bad;
           const double v = (int32_t)vcv < pl.dn[b] ? pl.dict[pl.doff[b] + vcv] : std::nan("");
           const int32_t c = (int32_t)lcv < pl.blkW[b] ? slot_col[lcv] : -1;
           if (c != col[rp[r] + k] || std::memcmp(&v, &val[rp[r] + k], 8) != 0) ++bad;

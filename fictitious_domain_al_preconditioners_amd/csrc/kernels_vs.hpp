@@ -8,11 +8,12 @@
 //    a third of that of 96 consecutive rows of a lexicographic numbering (825 instead of
 //    2 700 slots at 96 rows): less L2 -> LDS staging, less HBM re-fetch of x, and 8 resident
 //    waves per SIMD instead of 4.9 (the window no longer limits occupancy);
-//  * the 3 B/nnz stream (16-bit window column + 8-bit dictionary code) is stored BATCH-MAJOR:
-//    the rows of a block are grouped by chunk count into batches of 4.  A batch's FULL
-//    64-entry chunks are stored lane-major, the four rows interleaved (12 bytes per lane and
-//    chunk index: 4 window columns + 4 codes), so one global_load_dwordx3 replaces eight
-//    narrow loads; only the rows' last, partial chunks keep the compact (column, code) form.
+//  * the 3 B/nnz stream (12-bit window column + 9-bit dictionary code in 24 bits) is stored BATCH-MAJOR:
+//    the rows of a block are grouped by chunk count (and sorted by length) into batches of 4.
+//    A batch's 64-entry chunks are stored lane-major, the four rows interleaved (12 bytes
+//    per lane and chunk index: 4 x (12-bit window column + 9-bit code)), so one global_load_dwordx3
+//    replaces eight narrow loads; of the last, partial chunk only the lanes below the
+//    batch's longest remainder are stored.
 //    With the window small, the stream loads are what bounds the kernel (ablation: without
 //    them 0.61 ms, without the LDS gathers 1.29 of 1.30 ms), and a wave-level load costs the
 //    same ~8.5 issue cycles whether it carries 1 or 4 bytes per lane;
@@ -27,73 +28,65 @@
 
 namespace alfd {
 
-constexpr int kVsDictOff = 0;     // 256 dictionary doubles at LDS offset 0
-constexpr int kVsWinOff = 2048;   // the x window behind them
+constexpr int kVsMaxDict = 512;   // distinct values per block (9-bit codes)
+constexpr int kVsDictOff = 0;     // the block's dictionary at LDS offset 0
+constexpr int kVsWinOff = kVsMaxDict * 8;   // the x window behind it (at most 4096 slots: 12-bit columns)
 constexpr int kVsMaxRows = 250;   // rows per block
 constexpr int kVsMaxLen = 384;    // longest row the format takes (class 6)
 
-// batch descriptor, one uint64 per row: eb + t (20 bits) | entry count (9) | class = ceil(count / 64)
-// (3) | global row, 0xffffffff = filler (32).  eb: the batch's offset from the block's first
-// entry in padded entries (a multiple of 16; the batch starts at byte 3 eb), t: the offset of the
-// row's last chunk in the batch's tail.  Row 0 has t = 0; fillers repeat row 0.
+// batch descriptor, one uint64 per row: eb (20 bits) | entry count (9) | class = ceil(count / 64) (3)
+// | global row, 0xffffffff = filler (32).  eb: the batch's offset from the block's first entry in
+// 3-byte units (a multiple of 16: the batch starts at byte 3 eb).  Fillers repeat row 0.
 __device__ __forceinline__ uint32_t vs_off(uint64_t d) { return (uint32_t)d & 0xfffffu; }
 __device__ __forceinline__ int32_t vs_len(uint64_t d) { return (int32_t)(((uint32_t)d >> 20) & 0x1ffu); }
 __device__ __forceinline__ int vs_cls(uint64_t d) { return (int)(((uint32_t)d >> 29) & 7u); }
+
+// LDS read at a byte offset from the start of the workgroup's LDS (the kernel has no static
+// __shared__ data, so its dynamic array starts at 0): no symbol, so nothing is added to the offset
+__device__ __forceinline__ double vs_lds_f64(uint32_t byte_off) {
+  return *(const __attribute__((address_space(3))) double *)(uintptr_t)byte_off;
+}
 
 struct VsWord3 {
   uint32_t x, y, z;
 };
 
-// One batch of 4 rows with NCH chunks each.  fb: the batch's NCH-1 full chunks, lane-major -- for
-// chunk j, lane l holds at fb + 768 j + 12 l the window columns of rows 0..3 (4 x 16 bit) and their
-// codes (4 x 8 bit): ONE global_load_dwordx3 per chunk serves all four rows.  lc / vc: the rows'
-// last (partial) chunks, stored compactly; t[i] is row i's offset there, rem[i] its entry count.
+// One batch of 4 rows with NCH chunks each, stored lane-major with the four rows interleaved: for
+// chunk j, lane l holds at fb + 768 j + 12 l four 24-bit fields, one per row:
+//     f = (value code << 15) | (window column << 3)          (9-bit code, 12-bit column)
+// i.e. both LDS byte offsets ready-shifted: column offset = f & 0x7ff8, dictionary offset =
+// (f >> 12) & 0xff8.  ONE global_load_dwordx3 per chunk serves all four rows.  The last chunk is
+// partial: only lanes below the batch's longest remainder are stored (rows of a class are sorted by
+// length, so the remainders of a batch are equal or close); rem[i] masks row i's fma.
 // All loads of the batch are issued before the first use.
 template <int NCH>
-__device__ __forceinline__ void vs_batch(const uint32_t (&t)[4], const int32_t (&rem)[4], int lane,
-                                         const uint8_t *__restrict__ fb, const uint16_t *__restrict__ lc,
-                                         const uint8_t *__restrict__ vc, const char *sm, double (&acc)[4]) {
-  constexpr int NF = NCH - 1;
-  VsWord3 w[NF > 0 ? NF : 1];
+__device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem, int lane,
+                                         const uint8_t *__restrict__ fb, const char *sm, double (&acc)[4]) {
+  VsWord3 w[NCH];
 #pragma unroll
-  for (int j = 0; j < NF; ++j) w[j] = *(const VsWord3 *)(fb + 768 * j + 12 * lane);
-  int32_t c[4], iv[4];
-  bool ok[4];
+  for (int j = 0; j < NCH - 1; ++j) w[j] = *(const VsWord3 *)(fb + 768 * j + 12 * lane);
+  w[NCH - 1] = *(const VsWord3 *)(fb + 768 * (NCH - 1) + 12 * (lane < maxrem ? lane : maxrem - 1));
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ok[i] = lane < rem[i];
-    const uint32_t k = t[i] + (uint32_t)(ok[i] ? lane : 0);
-    c[i] = lc[k];
-    iv[i] = vc[k];
-  }
-#pragma unroll
-  for (int j = 0; j < NF; ++j) {
+  for (int j = 0; j < NCH; ++j) {
     double xv[4], v[4];
+    const uint32_t f[4] = {w[j].x, __builtin_amdgcn_alignbit(w[j].y, w[j].x, 24),
+                           __builtin_amdgcn_alignbit(w[j].z, w[j].y, 16), w[j].z >> 8};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const uint32_t cw = i < 2 ? w[j].x : w[j].y;
-      const uint32_t ci = (i & 1) ? (cw >> 16) : (cw & 0xffffu);
-      const uint32_t vi = (w[j].z >> (8 * i)) & 0xffu;
-      xv[i] = *(const double *)(sm + kVsWinOff + 8 * ci);
-      v[i] = *(const double *)(sm + kVsDictOff + 8 * vi);
+      xv[i] = vs_lds_f64(kVsWinOff + (f[i] & 0x7ff8u));
+      v[i] = vs_lds_f64(kVsDictOff + ((f[i] >> 12) & 0xff8u));
     }
+    // keep the eight gathers of the chunk ahead of the (masked) fmas
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[i]), "+v"(v[i]));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = fma(v[i], xv[i], acc[i]);
-  }
-  {
-    double xv[4], v[4];
-#pragma unroll
     for (int i = 0; i < 4; ++i) {
-      xv[i] = *(const double *)(sm + kVsWinOff + 8 * c[i]);
-      v[i] = *(const double *)(sm + kVsDictOff + 8 * iv[i]);
+      if (j == NCH - 1) {
+        if (lane < rem[i]) acc[i] = fma(v[i], xv[i], acc[i]);
+      } else {
+        acc[i] = fma(v[i], xv[i], acc[i]);
+      }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[i]), "+v"(v[i]));
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (ok[i]) acc[i] = fma(v[i], xv[i], acc[i]);
   }
 }
 
@@ -164,27 +157,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint32_t eb = vs_off(desc[0]);
     const int cls = vs_cls(desc[0]);
     const int32_t full = cls > 0 ? 64 * (cls - 1) : 0;
-    uint32_t end = 0, t[4];
-    int32_t rem[4];
+    int32_t rem[4], maxrem = 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      t[i] = vs_off(desc[i]) - eb;
       rem[i] = vs_len(desc[i]) - full;
-      const uint32_t e = t[i] + (uint32_t)rem[i];
-      end = e > end ? e : end;
+      maxrem = rem[i] > maxrem ? rem[i] : maxrem;
     }
-    const uint32_t T = (end + 15u) & ~15u;
     const uint8_t *fb = sbase + 3u * (size_t)eb;
-    const uint16_t *lc = (const uint16_t *)(fb + 768u * (uint32_t)(cls > 0 ? cls - 1 : 0));
-    const uint8_t *vc = (const uint8_t *)lc + 2u * (size_t)T;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     switch (cls) {
-      case 1: vs_batch<1>(t, rem, lane, fb, lc, vc, sm, acc); break;
-      case 2: vs_batch<2>(t, rem, lane, fb, lc, vc, sm, acc); break;
-      case 3: vs_batch<3>(t, rem, lane, fb, lc, vc, sm, acc); break;
-      case 4: vs_batch<4>(t, rem, lane, fb, lc, vc, sm, acc); break;
-      case 5: vs_batch<5>(t, rem, lane, fb, lc, vc, sm, acc); break;
-      case 6: vs_batch<6>(t, rem, lane, fb, lc, vc, sm, acc); break;
+      case 1: vs_batch<1>(rem, maxrem, lane, fb, sm, acc); break;
+      case 2: vs_batch<2>(rem, maxrem, lane, fb, sm, acc); break;
+      case 3: vs_batch<3>(rem, maxrem, lane, fb, sm, acc); break;
+      case 4: vs_batch<4>(rem, maxrem, lane, fb, sm, acc); break;
+      case 5: vs_batch<5>(rem, maxrem, lane, fb, sm, acc); break;
+      case 6: vs_batch<6>(rem, maxrem, lane, fb, sm, acc); break;
       default: break;  // class 0: empty rows
     }
     const double s = reduce_rows4(acc[0], acc[1], acc[2], acc[3]);

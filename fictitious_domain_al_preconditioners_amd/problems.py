@@ -349,22 +349,26 @@ def elasticity3d(n_bg=16, cells_fg=None, lame_bg=(2.0, 1.0), lame_fg=(20.0, 10.0
                     immersed_box3d=(box[0], box[1], cells_fg), row_ranges=row_ranges)
 
 
-def brick_row_blocks(params: dict, brick=(8, 2, 2), max_rows: int = 250):
+def brick_row_blocks(params: dict, brick=(8, 4, 2), max_rows: int = 250, node_range=None):
     """Row blocks for Context.set_row_blocks (alfd_set_row_blocks) on the tensor-grid background space:
     the nodes of a brick[0] x brick[1] (x brick[2]) patch of the grid, all components of a node together
-    (node-major, the numbering of the block-(0,0) operator).  Returns (block_ptr, rows)."""
+    (node-major, the numbering of the block-(0,0) operator).  node_range = (first, last+1) restricts the
+    blocks to one rank's slab of nodes (rows are then numbered from that slab's first row).
+    Returns (block_ptr, rows)."""
     dim, ncomp = params["dim"], params["ncomp"]
     n1 = params["degree"] * params["n_cells"] + 1
-    idx = np.arange(n1 ** dim, dtype=np.int64)
+    n0, n_end = (0, n1 ** dim) if node_range is None else (int(node_range[0]), int(node_range[1]))
+    idx = np.arange(n0, n_end, dtype=np.int64)
     key = np.zeros(idx.size, np.int64)
     for d in reversed(range(dim)):
         c = (idx // n1 ** d) % n1
         key = key * (n1 // brick[d] + 1) + c // brick[d]
     order = np.argsort(key, kind="stable")                    # nodes of a brick keep their lexicographic order
-    starts = np.flatnonzero(np.r_[True, key[order][1:] != key[order][:-1]])
+    sk = key[order]
+    starts = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]])
     node_ptr = np.r_[starts, idx.size]
     per = max(1, max_rows // ncomp)
-    if np.max(np.diff(node_ptr)) > per:                       # split oversized bricks
+    if idx.size and np.max(np.diff(node_ptr)) > per:          # split oversized bricks
         cuts = [np.arange(a, b, per) for a, b in zip(node_ptr[:-1], node_ptr[1:])]
         node_ptr = np.r_[np.concatenate(cuts), idx.size]
     rows = (order[:, None] * ncomp + np.arange(ncomp)[None, :]).astype(np.int32).ravel()

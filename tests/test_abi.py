@@ -79,6 +79,41 @@ def test_product_package_never_imports_the_oracle():
                 assert not hits, (os.path.join(dirpath, f), hits)
 
 
+def test_host_stream_plan_decodes_back():
+    """The batch-major value-indexed storage (kernels_vs.hpp) planned on the host decodes back to the
+    CSR it was made from -- rows through the batch descriptors, lane-major chunks, window segments,
+    dictionaries -- for runs of the numbering, mesh bricks, ragged caller blocks; blocks with more than
+    512 distinct values are halved; a matrix with unrelated values is refused.  No GPU involved."""
+    import numpy as np
+    from fictitious_domain_al_preconditioners_amd import problems
+    pb = problems.generate(dim=3, degree=2, ncomp=3, n_cells=6, stokes=False, grad_div=True,
+                           gamma_grad_div=10.0, radius=0.1, immersed_refine=0)
+    a = pb.mats["A"]
+    runs = solver.host_stream_plan(a)
+    assert runs["ok"] and runs["decode_mismatches"] == 0 and runs["rows_covered"] == a.nrows
+    assert runs["blocks"] >= -(-a.nrows // 96) and runs["max_rows"] <= 96
+    assert 3.0 * a.nnz <= runs["stream_bytes"] < 3.6 * a.nnz
+    bricks = solver.host_stream_plan(a, blocks=problems.brick_row_blocks(pb.params, (8, 4, 2)))
+    assert bricks["ok"] and bricks["decode_mismatches"] == 0 and bricks["rows_covered"] == a.nrows
+    assert bricks["max_window"] < runs["max_window"]                # what the bricks are for (a third on large grids)
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(a.nrows)
+    perm = perm[np.argsort(perm // 40, kind="stable")]               # shuffled inside groups of 40 rows
+    ptr = np.unique(np.r_[0, np.cumsum(rng.integers(1, 60, a.nrows // 20)), a.nrows])
+    ptr = ptr[ptr <= a.nrows]
+    ragged = solver.host_stream_plan(a, blocks=(ptr, perm))
+    assert ragged["ok"] and ragged["decode_mismatches"] == 0 and ragged["rows_covered"] == a.nrows
+    # every value scaled by one of 16 factors: blocks exceed the 512 dictionary entries and are halved
+    v = np.array(a.val) * (1.0 + 0.0625 * rng.integers(0, 16, a.nnz))
+    many = problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), v)
+    info = solver.host_stream_plan(many)
+    assert info["ok"] and info["decode_mismatches"] == 0 and info["rows_covered"] == a.nrows
+    assert info["blocks"] > runs["blocks"] and info["dictionary_entries"] <= 512 * info["blocks"]
+    # unrelated values: not representable (the library keeps the other formats)
+    rnd = problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), rng.uniform(-1, 1, a.nnz))
+    assert not solver.host_stream_plan(rnd)["ok"]
+
+
 def test_host_window_plan_decodes_back():
     """The LDS-window / value-indexed storage planned on the host (what alfd_set_matrix uploads)
     decodes back to the CSR it was made from: window columns, dictionary values (8-bit, 16-bit,
