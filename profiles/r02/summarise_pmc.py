@@ -10,7 +10,7 @@ kernel = None
 for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        if "spmv_window" not in k:
+        if "spmv_window" not in k and "spmv_vs_kernel" not in k:
             continue
         kernel = kernel or k
         rows.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
