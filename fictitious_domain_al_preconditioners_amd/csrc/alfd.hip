@@ -4069,6 +4069,125 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   return ALFD_OK;
 }
 
+// Recursive coordinate bisection of the rows' support points: leaves of at most max_rows rows, cut at the
+// median of the axis with the largest (weighted) extent.  The axis along which consecutive rows mostly
+// advance -- the fast axis of the numbering -- counts half, so that bricks come out about twice as long
+// there: the x window of a block is staged in runs of consecutive columns.
+namespace {
+struct Rcb {
+  int dim;
+  const double *xyz;
+  int64_t max_rows;
+  double weight[3];
+  std::vector<int32_t> idx;
+  std::vector<std::vector<int64_t>> leaves;   // leaf sizes per top-level task, in order
+  void split(int64_t a, int64_t e, std::vector<int64_t> &out) {
+    if (e - a <= max_rows) {
+      if (e > a) out.push_back(e - a);
+      return;
+    }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = a; i < e; ++i)
+      for (int d = 0; d < dim; ++d) {
+        const double c = xyz[(int64_t)idx[i] * dim + d];
+        lo[d] = std::min(lo[d], c);
+        hi[d] = std::max(hi[d], c);
+      }
+    int ax = 0;
+    for (int d = 1; d < dim; ++d)
+      if ((hi[d] - lo[d]) * weight[d] > (hi[ax] - lo[ax]) * weight[ax]) ax = d;
+    // cut so that the left part holds a multiple of max_rows/2 rows when possible (fewer ragged leaves)
+    const int64_t mid = a + (e - a) / 2;
+    std::nth_element(idx.begin() + a, idx.begin() + mid, idx.begin() + e, [&](int32_t p, int32_t q) {
+      const double cp = xyz[(int64_t)p * dim + ax], cq = xyz[(int64_t)q * dim + ax];
+      return cp < cq || (cp == cq && p < q);
+    });
+    split(a, mid, out);
+    split(mid, e, out);
+  }
+};
+}  // namespace
+
+int alfd_host_row_blocks_from_points(int64_t nrows, int32_t dim, const double *points, int32_t max_rows,
+                                     int64_t *n_blocks_out, int64_t *block_ptr_out, int32_t *rows_out) {
+  if (nrows < 0 || dim < 1 || dim > 3 || !points || max_rows < 1 || max_rows > kVsMaxRows || !n_blocks_out ||
+      !block_ptr_out || !rows_out || nrows > 2147483000LL)
+    return ALFD_E_INVALID;
+  Rcb r;
+  r.dim = dim;
+  r.xyz = points;
+  r.max_rows = max_rows;
+  r.idx.resize(nrows);
+  for (int64_t i = 0; i < nrows; ++i) r.idx[i] = (int32_t)i;
+  // fast axis of the numbering: the axis along which consecutive rows most often differ
+  int64_t moves[3] = {0, 0, 0};
+  for (int64_t i = 0; i + 1 < nrows; i += std::max<int64_t>(1, nrows / 100000)) {
+    int best = -1;
+    double bd = 0;
+    for (int d = 0; d < dim; ++d) {
+      const double dd = std::fabs(points[(i + 1) * dim + d] - points[i * dim + d]);
+      if (dd > bd) bd = dd, best = d;
+    }
+    if (best >= 0) ++moves[best];
+  }
+  int fast = 0;
+  for (int d = 1; d < dim; ++d)
+    if (moves[d] > moves[fast]) fast = d;
+  for (int d = 0; d < 3; ++d) r.weight[d] = d == fast ? 0.5 : 1.0;
+  // top levels sequentially into 2^k tasks, the tasks in parallel
+  std::vector<std::pair<int64_t, int64_t>> tasks(1, {0, nrows});
+  const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  while ((int)tasks.size() < T && nrows > (int64_t)max_rows * 64) {
+    std::vector<std::pair<int64_t, int64_t>> next;
+    for (auto [a, e] : tasks) {
+      if (e - a <= max_rows) {
+        next.push_back({a, e});
+        continue;
+      }
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+      for (int64_t i = a; i < e; ++i)
+        for (int d = 0; d < dim; ++d) {
+          const double c = points[(int64_t)r.idx[i] * dim + d];
+          lo[d] = std::min(lo[d], c);
+          hi[d] = std::max(hi[d], c);
+        }
+      int ax = 0;
+      for (int d = 1; d < dim; ++d)
+        if ((hi[d] - lo[d]) * r.weight[d] > (hi[ax] - lo[ax]) * r.weight[ax]) ax = d;
+      const int64_t mid = a + (e - a) / 2;
+      std::nth_element(r.idx.begin() + a, r.idx.begin() + mid, r.idx.begin() + e, [&](int32_t p, int32_t q) {
+        const double cp = points[(int64_t)p * dim + ax], cq = points[(int64_t)q * dim + ax];
+        return cp < cq || (cp == cq && p < q);
+      });
+      next.push_back({a, mid});
+      next.push_back({mid, e});
+    }
+    tasks.swap(next);
+  }
+  r.leaves.assign(tasks.size(), {});
+  {
+    std::vector<std::thread> th;
+    std::atomic<size_t> nextTask(0);
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&]() {
+        for (size_t q = nextTask++; q < tasks.size(); q = nextTask++) r.split(tasks[q].first, tasks[q].second, r.leaves[q]);
+      });
+    for (auto &x : th) x.join();
+  }
+  int64_t nb = 0;
+  block_ptr_out[0] = 0;
+  for (auto &lv : r.leaves)
+    for (int64_t sz : lv) {
+      block_ptr_out[nb + 1] = block_ptr_out[nb] + sz;
+      ++nb;
+    }
+  // rows of a block in ascending order (the order the numbering visits them)
+  for (int64_t b = 0; b < nb; ++b) std::sort(r.idx.begin() + block_ptr_out[b], r.idx.begin() + block_ptr_out[b + 1]);
+  std::copy(r.idx.begin(), r.idx.end(), rows_out);
+  *n_blocks_out = nb;
+  return ALFD_OK;
+}
+
 int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int32_t row_block,
                           int64_t n_blocks, const int64_t *block_ptr, const int32_t *rows,
                           alfd_stream_plan_info *out) {

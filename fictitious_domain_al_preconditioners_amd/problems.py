@@ -349,6 +349,19 @@ def elasticity3d(n_bg=16, cells_fg=None, lame_bg=(2.0, 1.0), lame_fg=(20.0, 10.0
                     immersed_box3d=(box[0], box[1], cells_fg), row_ranges=row_ranges)
 
 
+def row_support_points(params: dict, node_range=None):
+    """One support point per row of the block-(0,0) operator of a tensor-grid problem (node-major
+    numbering: the ncomp rows of a node share its point) -- what DoFTools::map_dofs_to_support_points
+    gives a deal.II caller; input of solver.row_blocks_from_points."""
+    dim, ncomp = params["dim"], params["ncomp"]
+    n1 = params["degree"] * params["n_cells"] + 1
+    n0, n_end = (0, n1 ** dim) if node_range is None else (int(node_range[0]), int(node_range[1]))
+    idx = np.arange(n0, n_end, dtype=np.int64)
+    h = (params["hi"] - params["lo"]) / (n1 - 1)
+    pts = np.stack([params["lo"] + h * ((idx // n1 ** d) % n1) for d in range(dim)], axis=1)
+    return np.repeat(pts, ncomp, axis=0)
+
+
 def brick_row_blocks(params: dict, brick=(8, 4, 2), max_rows: int = 250, node_range=None):
     """Row blocks for Context.set_row_blocks (alfd_set_row_blocks) on the tensor-grid background space:
     the nodes of a brick[0] x brick[1] (x brick[2]) patch of the grid, all components of a node together

@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "alfd_host_window_plan", "alfd_set_tunable", "alfd_build_aggregates", "alfd_get_aggregates",
     "alfd_host_aggregate_level", "alfd_comm_init_host",
     "alfd_get_device_memory", "alfd_set_row_blocks", "alfd_host_stream_plan",
+    "alfd_host_row_blocks_from_points",
 ]
 
 
@@ -104,6 +105,7 @@ def load_library():
         "alfd_get_device_memory": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "alfd_set_row_blocks": (C.c_int, [vp, C.c_int, i64, vp, vp]),
         "alfd_host_stream_plan": (C.c_int, [i64, vp, vp, vp, C.c_int32, i64, vp, vp, vp]),
+        "alfd_host_row_blocks_from_points": (C.c_int, [i64, C.c_int32, vp, C.c_int32, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -410,6 +412,22 @@ def host_window_plan(m, lanes=64, value_index=True):
     if rc != _abi.OK:
         raise AlfdError(rc, "alfd_host_window_plan failed")
     return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+def row_blocks_from_points(points, max_rows=192):
+    """(block_ptr, rows) for Context.set_row_blocks from one support point per matrix row
+    (alfd_host_row_blocks_from_points: recursive coordinate bisection, no grid metadata needed)."""
+    lib = load_library()
+    pts = np.ascontiguousarray(points, np.float64)
+    n, dim = pts.shape
+    ptr = np.zeros(n + 1, np.int64)
+    rows = np.zeros(n, np.int32)
+    nb = C.c_int64(0)
+    rc = lib.alfd_host_row_blocks_from_points(n, dim, pts.ctypes.data, max_rows, C.byref(nb), ptr.ctypes.data,
+                                              rows.ctypes.data)
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_row_blocks_from_points failed")
+    return ptr[:nb.value + 1].copy(), rows
 
 
 def host_stream_plan(m, row_block=96, blocks=None):

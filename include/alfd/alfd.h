@@ -409,6 +409,13 @@ int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value
  * removes the hint (blocks are then runs of the row numbering). */
 int alfd_set_row_blocks(alfd_ctx_t ctx, int slot, int64_t n_blocks, const int64_t *block_ptr, const int32_t *rows);
 
+/* Host-only helper for alfd_set_row_blocks when the caller has no grid metadata: recursive coordinate
+ * bisection of one support point per matrix row (deal.II: DoFTools::map_dofs_to_support_points) into
+ * blocks of at most max_rows (<= 250) rows.  block_ptr_out needs room for nrows + 1 entries, rows_out
+ * for nrows; *n_blocks_out receives the number of blocks. */
+int alfd_host_row_blocks_from_points(int64_t nrows, int32_t dim, const double *points, int32_t max_rows,
+                                     int64_t *n_blocks_out, int64_t *block_ptr_out, int32_t *rows_out);
+
 /* Free / total bytes of the context's device (hipMemGetInfo): leak checks, capacity planning. */
 int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_bytes);
 /* Run-time switches of a context (measurement and A/B comparison; results never change):

@@ -100,6 +100,27 @@ class System {
     check(alfd_set_diag(ctx_, slot, (int64_t)d.size(), &*d.begin()));
   }
 
+  // Row blocks of the SpMV on `slot` (alfd_set_row_blocks) from one support point per row, e.g.
+  //   std::map<types::global_dof_index, Point<dim>> sp;  DoFTools::map_dofs_to_support_points(mapping, dh, sp);
+  // restricted to the velocity block.  Call before set_matrix(slot, ...).  A block stages one window of x
+  // in LDS: spatially compact blocks (recursive coordinate bisection here) keep that window a third of
+  // what a run of consecutive DoF indices needs.  Does not change any result.
+  template <class PointContainer>
+  void set_row_blocks_from_support_points(int slot, const PointContainer &points, int dim, int max_rows = 192) {
+    const int64_t n = (int64_t)points.size();
+    std::vector<double> xyz((size_t)n * dim);
+    int64_t i = 0;
+    for (const auto &p : points) {
+      for (int d = 0; d < dim; ++d) xyz[(size_t)i * dim + d] = p[d];
+      ++i;
+    }
+    std::vector<int64_t> ptr((size_t)n + 1);
+    std::vector<int32_t> rows((size_t)n);
+    int64_t nb = 0;
+    check(alfd_host_row_blocks_from_points(n, dim, xyz.data(), max_rows, &nb, ptr.data(), rows.data()));
+    check(alfd_set_row_blocks(ctx_, slot, nb, ptr.data(), rows.data()));
+  }
+
   // Aggregates of the multilevel inner preconditioner (ALFD_PREC_MULTILEVEL; replaces the ML
   // aggregation of utilities.h:304-317).  weights may be empty (constant modes).
   void set_aggregates(int level, const std::vector<int32_t> &agg, int64_t n_coarse,

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -194,6 +195,14 @@ int main(int argc, char **argv) {
       return 0;
     }
     System sys(0);
+    {
+      // support points of the background DoFs (DoFTools::map_dofs_to_support_points): spatially compact row
+      // blocks for the SpMV on A; only long-row operators (3-D vector Q2) use them, results never change
+      const int n1 = sp.n_cells + 1;
+      std::vector<std::array<double, 2>> support_points(n_u);
+      for (size_t i = 0; i < n_u; ++i) support_points[i] = {(double)(i % n1) / sp.n_cells, (double)(i / n1) / sp.n_cells};
+      sys.set_row_blocks_from_support_points(ALFD_A, support_points, 2);
+    }
     sys.set_matrix(ALFD_A, stiffness_matrix);
     sys.set_matrix(ALFD_CT, coupling_matrix);     // C = transpose_operator(Ct) is derived
     sys.set_diag(ALFD_INVW, inv_diagonal);

@@ -114,6 +114,33 @@ def test_host_stream_plan_decodes_back():
     assert not solver.host_stream_plan(rnd)["ok"]
 
 
+def test_row_blocks_from_support_points():
+    """alfd_host_row_blocks_from_points: a partition of the rows into spatially compact blocks of at most
+    max_rows rows, usable as alfd_set_row_blocks input without grid metadata (window well below that of
+    runs of the numbering)."""
+    import numpy as np
+    from fictitious_domain_al_preconditioners_amd import problems
+    pb = problems.generate(dim=3, degree=2, ncomp=3, n_cells=10, stokes=False, grad_div=True,
+                           gamma_grad_div=10.0, radius=0.1, immersed_refine=0)
+    a = pb.mats["A"]
+    pts = problems.row_support_points(pb.params)
+    assert pts.shape == (a.nrows, 3)
+    ptr, rows = solver.row_blocks_from_points(pts, 192)
+    assert ptr[0] == 0 and ptr[-1] == a.nrows and np.all(np.diff(ptr) > 0) and np.max(np.diff(ptr)) <= 192
+    assert np.array_equal(np.sort(rows), np.arange(a.nrows))
+    for b in (0, len(ptr) // 2, len(ptr) - 2):                       # rows of a block are close in space
+        ext = np.ptp(pts[rows[ptr[b]:ptr[b + 1]]], axis=0)
+        assert np.all(ext <= 0.55), ext
+    rcb = solver.host_stream_plan(a, blocks=(ptr, rows))
+    runs = solver.host_stream_plan(a)
+    assert rcb["ok"] and rcb["decode_mismatches"] == 0 and rcb["rows_covered"] == a.nrows
+    assert rcb["max_window"] < runs["max_window"]
+    # 2-D points, tiny input, one block
+    p2 = np.stack([np.arange(7.0), np.zeros(7)], axis=1)
+    ptr, rows = solver.row_blocks_from_points(p2, 250)
+    assert list(ptr) == [0, 7] and sorted(rows) == list(range(7))
+
+
 def test_host_window_plan_decodes_back():
     """The LDS-window / value-indexed storage planned on the host (what alfd_set_matrix uploads)
     decodes back to the CSR it was made from: window columns, dictionary values (8-bit, 16-bit,

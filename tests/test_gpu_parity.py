@@ -53,7 +53,7 @@ def test_spmv_bitwise(ctxs, name, mode):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("blocks", ["runs", "bricks", "bricks444", "ragged"])
+@pytest.mark.parametrize("blocks", ["runs", "bricks", "bricks444", "ragged", "rcb"])
 def test_batch_major_format_bitwise(built, blocks):
     """The batch-major value-indexed format (kernels_vs.hpp, tunable batch_major): row blocks as runs of
     the numbering, as mesh bricks handed in through alfd_set_row_blocks, and as ragged random-size
@@ -70,6 +70,8 @@ def test_batch_major_format_bitwise(built, blocks):
         elif blocks == "bricks444":
             ctx.set_tunable("batch_major_waves", 8)
             ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(big.params, (4, 4, 4)))
+        elif blocks == "rcb":
+            ctx.set_row_blocks(_abi.A, *solver.row_blocks_from_points(problems.row_support_points(big.params), 192))
         elif blocks == "ragged":
             perm = np.argsort((np.arange(m.nrows) // 32) * 1000 + rng.integers(0, 1000, m.nrows), kind="stable")
             sizes = rng.integers(1, 48, m.nrows // 16)
