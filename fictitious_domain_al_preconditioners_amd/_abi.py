@@ -99,6 +99,7 @@ class StreamPlanInfo(C.Structure):
         ("ok", C.c_int32), ("max_window", C.c_int32), ("max_rows", C.c_int32), ("max_batches", C.c_int32),
         ("blocks", C.c_int64), ("batches", C.c_int64), ("segments", C.c_int64), ("dictionary_entries", C.c_int64),
         ("stream_bytes", C.c_int64), ("decode_mismatches", C.c_int64), ("rows_covered", C.c_int64),
+        ("shared_nnz", C.c_int64),
     ]
 
 

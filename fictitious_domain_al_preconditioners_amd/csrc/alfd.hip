@@ -98,7 +98,7 @@ struct DevCsr {
   // batch-major format (spmv_vs_kernel, kernels_vs.hpp)
   struct Vs {
     bool on = false, bricks = false;
-    int64_t nb = 0, nseg = 0, stream_bytes = 0, nbatch = 0, dict_total = 0;
+    int64_t nb = 0, nseg = 0, stream_bytes = 0, nbatch = 0, dict_total = 0, shared_nnz = 0;
     int32_t stride = 0, maxW = 0;
     uint8_t *stream = nullptr;
     int64_t *sb = nullptr;
@@ -1896,7 +1896,7 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
 // kVsMaxLen entries; otherwise the matrix keeps the formats of plan_window.
 struct VsPlan {
   bool ok = false;
-  int64_t nb = 0, nbatch = 0;
+  int64_t nb = 0, nbatch = 0, shared_nnz = 0;
   int rbs = 0, stride = 0;
   int32_t maxW = 0;
   std::vector<int32_t> blkW, seg_begin, seg_col, seg_off, doff, dn, cnt;
@@ -1908,35 +1908,143 @@ struct VsPlan {
 
 struct VsBatch {
   int cls, nreal, id[4];
+  bool shared;        // the rows are translates of one another: one template + a window shift per row
+  int32_t shift[4];   // window slots, relative to row id[0]
 };
-// class-sorted batches of one block (rows given by their block-local ids 0..nr-1 and lengths)
-static bool vs_batches(int nr, const int64_t *len, std::vector<VsBatch> &out) {
+
+// x window of a row block: maximal runs of used columns, gaps shorter than GAP bridged, cut into pieces
+// of at most 64 slots (one wave-load each).  pos[c - clo] = window slot of column c.
+struct VsWindow {
+  int32_t clo = 0, W = 0, nseg = 0;
+  std::vector<int32_t> pos;
+  std::vector<uint8_t> mark;
+};
+static bool vs_window(const std::vector<int32_t> &rows, const int64_t *rp, const int32_t *col, int GAP, int maxW,
+                      VsWindow &w, std::vector<int32_t> *seg_col, std::vector<int32_t> *seg_off) {
+  int32_t clo = INT32_MAX, chi = -1;
+  for (int32_t r : rows)
+    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+      clo = std::min(clo, col[k]);
+      chi = std::max(chi, col[k]);
+    }
+  const int64_t range = chi < 0 ? 0 : (int64_t)chi - clo + 1;
+  if (range > (int64_t)(1 << 24)) return false;
+  w.clo = chi < 0 ? 0 : clo;
+  w.mark.assign(range, 0);
+  for (int32_t r : rows)
+    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) w.mark[col[k] - clo] = 1;
+  w.pos.assign(range, -1);
+  w.W = 0;
+  w.nseg = 0;
+  int64_t c = 0;
+  while (c < range) {
+    if (!w.mark[c]) {
+      ++c;
+      continue;
+    }
+    int64_t e = c, last = c;
+    while (e < range) {
+      if (w.mark[e]) last = e;
+      else if (e - last >= GAP) break;
+      ++e;
+    }
+    for (int64_t q0 = c; q0 <= last; q0 += 64) {
+      if (seg_col) {
+        seg_col->push_back((int32_t)(clo + q0));
+        seg_off->push_back(w.W + (int32_t)(q0 - c));
+      }
+      ++w.nseg;
+    }
+    for (int64_t q = c; q <= last; ++q) w.pos[q] = w.W++;
+    c = last + 1;
+  }
+  return w.W <= maxW && w.W <= 4096;
+}
+
+// Batches of one block.  Rows are grouped by chunk count (class); inside a class, rows that are
+// translates of one another -- same length, same values entry by entry, window columns differing by one
+// constant -- form SHARED batches (one stored template, a shift per row: what a uniform mesh gives for
+// the rows of one node type inside a brick); the rest form plain batches, longest rows first.
+static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, const int32_t *col, const double *val,
+                       const VsWindow &w, std::vector<VsBatch> &out) {
+  const int nr = (int)rows.size();
   out.clear();
-  for (int i = 0; i < nr; ++i)
-    if (len[i] > kVsMaxLen) return false;
-  std::vector<int> ids;
+  std::vector<int64_t> len(nr);
+  std::vector<uint64_t> key(nr);
+  std::vector<int32_t> first(nr, 0);
+  for (int i = 0; i < nr; ++i) {
+    const int64_t k0 = rp[rows[i]], n = rp[rows[i] + 1] - k0;
+    if (n > kVsMaxLen) return false;
+    len[i] = n;
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+    const int32_t p0 = n ? w.pos[col[k0] - w.clo] : 0;
+    first[i] = p0;
+    for (int64_t k = 0; k < n; ++k) {
+      uint64_t bits;
+      std::memcpy(&bits, &val[k0 + k], 8);
+      h = (h ^ bits) * 0xff51afd7ed558ccdull;
+      h = (h ^ (uint64_t)(uint32_t)(w.pos[col[k0 + k] - w.clo] - p0)) * 0xc4ceb9fe1a85ec53ull;
+      h ^= h >> 29;
+    }
+    key[i] = h;
+  }
+  auto same = [&](int a, int b) {   // exact test behind the hash
+    if (len[a] != len[b]) return false;
+    const int64_t ka = rp[rows[a]], kb = rp[rows[b]];
+    for (int64_t k = 0; k < len[a]; ++k) {
+      if (std::memcmp(&val[ka + k], &val[kb + k], 8) != 0) return false;
+      if (w.pos[col[ka + k] - w.clo] - first[a] != w.pos[col[kb + k] - w.clo] - first[b]) return false;
+    }
+    return true;
+  };
+  std::vector<int> ids, plain;
   for (int cls = 0; cls <= 6; ++cls) {
     ids.clear();
+    plain.clear();
     for (int i = 0; i < nr; ++i)
       if ((int)((len[i] + 63) / 64) == cls) ids.push_back(i);
-    // longest first: the rows of a batch then have equal or close remainders in the last chunk
-    std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return len[a] > len[b]; });
-    for (size_t q = 0; q < ids.size(); q += 4) {
-      VsBatch bt{cls, 0, {0, 0, 0, 0}};
-      for (size_t i = q; i < std::min(q + 4, ids.size()); ++i) bt.id[bt.nreal++] = ids[i];
+    if (cls == 0) {
+      plain = ids;
+    } else {
+      std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return key[a] < key[b]; });
+      size_t g0 = 0;
+      while (g0 < ids.size()) {
+        size_t g1 = g0 + 1;
+        while (g1 < ids.size() && key[ids[g1]] == key[ids[g0]] && same(ids[g0], ids[g1])) ++g1;
+        size_t q = g0;
+        for (; q + 2 <= g1; q += 4) {   // 2..4 rows per shared batch
+          VsBatch bt{cls, 0, {0, 0, 0, 0}, true, {0, 0, 0, 0}};
+          for (size_t i = q; i < std::min(q + 4, g1); ++i) {
+            bt.id[bt.nreal] = ids[i];
+            bt.shift[bt.nreal] = first[ids[i]] - first[ids[q]];
+            ++bt.nreal;
+          }
+          out.push_back(bt);
+        }
+        for (; q < g1; ++q) plain.push_back(ids[q]);
+        g0 = g1;
+      }
+    }
+    // plain batches: longest first, so that the rows of a batch have equal or close remainders in the last chunk
+    std::stable_sort(plain.begin(), plain.end(), [&](int a, int b) { return len[a] != len[b] ? len[a] > len[b] : a < b; });
+    for (size_t q = 0; q < plain.size(); q += 4) {
+      VsBatch bt{cls, 0, {0, 0, 0, 0}, false, {0, 0, 0, 0}};
+      for (size_t i = q; i < std::min(q + 4, plain.size()); ++i) bt.id[bt.nreal++] = plain[i];
       out.push_back(bt);
     }
   }
   return true;
 }
 
-// 3-byte units a batch occupies: 4 row slots x (full chunks + the longest remainder, rounded up to 4 lanes)
-static int64_t vs_batch_units(const VsBatch &q, const int64_t *len) {
+// 16-byte units a batch occupies.  Plain: 12 bytes (4 row slots x 24 bits) per lane and chunk; shared: 4 bytes
+// (one 24-bit field in a dword).  Of the last chunk only the lanes below the longest remainder (rounded up to 4).
+static int64_t vs_batch_units(const VsBatch &q, const std::vector<int32_t> &rows, const int64_t *rp) {
   if (q.cls == 0) return 0;
   const int64_t full = 64 * (q.cls - 1);
   int64_t mr = 1;
-  for (int i = 0; i < q.nreal; ++i) mr = std::max(mr, len[q.id[i]] - full);
-  return 4 * (full + (mr + 3) / 4 * 4);
+  for (int i = 0; i < q.nreal; ++i) mr = std::max(mr, rp[rows[q.id[i]] + 1] - rp[rows[q.id[i]]] - full);
+  const int64_t lanes = full + (mr + 3) / 4 * 4;
+  return q.shared ? lanes / 4 : 3 * lanes / 4;
 }
 
 // Blocks whose entries take more than kVsMaxDict distinct values (9-bit codes), or that list more than
@@ -2020,46 +2128,51 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
   const int32_t *brows = r_rows.data();
   const int64_t nb = (int64_t)r_ptr.size() - 1;
   if (nb == 0 || nb > 2147483000LL) return;
-  auto blk_rows = [&](int64_t b, std::vector<int32_t> &rows) { rows.assign(brows + bptr[b], brows + bptr[b + 1]); };
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  // pass 1: batch counts and stream extents
-  std::vector<int64_t> blk_entries(nb, 0);
-  std::vector<int32_t> blk_nbatch(nb, 0), blk_nrows(nb, 0);
+  // pass 1: windows, batches (kept), stream extents
+  std::vector<std::vector<VsBatch>> batches(nb);
+  std::vector<int64_t> blk_units(nb, 0);
   std::atomic<bool> bad(false);
+  std::atomic<int64_t> n_shared_nnz(0);
   {
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
       th.emplace_back([&, t]() {
         std::vector<int32_t> rows;
-        std::vector<int64_t> len;
-        std::vector<VsBatch> bts;
+        VsWindow w;
+        int64_t sh = 0;
         for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
-          blk_rows(b, rows);
-          if (rows.size() > (size_t)kVsMaxRows) { bad = true; break; }
-          len.resize(rows.size());
-          for (size_t i = 0; i < rows.size(); ++i) len[i] = rp[rows[i] + 1] - rp[rows[i]];
-          if (!vs_batches((int)rows.size(), len.data(), bts)) { bad = true; break; }
+          rows.assign(brows + bptr[b], brows + bptr[b + 1]);
+          if (rows.size() > (size_t)kVsMaxRows || !vs_window(rows, rp, col, GAP, maxW, w, nullptr, nullptr) ||
+              !vs_batches(rows, rp, col, val, w, batches[b])) {
+            bad = true;
+            break;
+          }
           int64_t e = 0;
-          for (const VsBatch &q : bts) e += vs_batch_units(q, len.data());
-          blk_entries[b] = e;
-          blk_nbatch[b] = (int32_t)bts.size();
-          blk_nrows[b] = (int32_t)rows.size();
+          for (const VsBatch &q : batches[b]) {
+            e += vs_batch_units(q, rows, rp);
+            if (q.shared)
+              for (int i = 0; i < q.nreal; ++i) sh += rp[rows[q.id[i]] + 1] - rp[rows[q.id[i]]];
+          }
+          blk_units[b] = e;
         }
+        n_shared_nnz += sh;
       });
     for (auto &x : th) x.join();
   }
   if (bad) return;
   pl.nb = nb;
+  pl.shared_nnz = n_shared_nnz;
   pl.sb.assign(nb, 0);
   int64_t tot = 0;
   int maxb = 1, maxr = 1;
   for (int64_t b = 0; b < nb; ++b) {
     pl.sb[b] = tot;
-    tot += 3 * blk_entries[b];
-    if (blk_entries[b] > 0xfffffLL) return;
-    maxb = std::max(maxb, (int)blk_nbatch[b]);
-    maxr = std::max(maxr, (int)blk_nrows[b]);
-    pl.nbatch += blk_nbatch[b];
+    tot += 16 * blk_units[b];
+    if (blk_units[b] > 0xfffffLL) return;
+    maxb = std::max(maxb, (int)batches[b].size());
+    maxr = std::max(maxr, (int)(bptr[b + 1] - bptr[b]));
+    pl.nbatch += (int64_t)batches[b].size();
   }
   if (maxb > 0xffff) return;
   pl.stride = maxb;
@@ -2076,101 +2189,70 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
       th.emplace_back([&, t]() {
-        std::vector<int32_t> rows, pos;
-        std::vector<int64_t> len;
-        std::vector<VsBatch> bts;
-        std::vector<uint8_t> mark;
+        std::vector<int32_t> rows;
+        VsWindow w;
         constexpr int kTab = 1024;
         std::vector<uint64_t> keys(kTab);
         std::vector<int16_t> ids(kTab);
         for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
-          blk_rows(b, rows);
-          const int nr = (int)rows.size();
-          len.resize(nr);
-          int32_t clo = INT32_MAX, chi = -1;
-          for (int i = 0; i < nr; ++i) {
-            len[i] = rp[rows[i] + 1] - rp[rows[i]];
-            for (int64_t k = rp[rows[i]]; k < rp[rows[i] + 1]; ++k) {
-              clo = std::min(clo, col[k]);
-              chi = std::max(chi, col[k]);
-            }
-          }
-          vs_batches(nr, len.data(), bts);
+          rows.assign(brows + bptr[b], brows + bptr[b + 1]);
+          const std::vector<VsBatch> &bts = batches[b];
           pl.cnt[b] = (int32_t)bts.size();
           t_doff[t].push_back((int32_t)t_dict[t].size());
-          // x window: maximal runs of used columns, gaps shorter than GAP bridged
-          const int64_t range = chi < 0 ? 0 : (int64_t)chi - clo + 1;
-          if (range > (int64_t)(1 << 24)) { bad = true; break; }
-          mark.assign(range, 0);
-          for (int i = 0; i < nr; ++i)
-            for (int64_t k = rp[rows[i]]; k < rp[rows[i] + 1]; ++k) mark[col[k] - clo] = 1;
-          pos.assign(range, -1);
-          int32_t W = 0, nseg = 0;
-          int64_t c = 0;
-          while (c < range) {
-            if (!mark[c]) {
-              ++c;
-              continue;
-            }
-            int64_t e = c, last = c;
-            while (e < range) {
-              if (mark[e]) last = e;
-              else if (e - last >= GAP) break;
-              ++e;
-            }
-            for (int64_t q0 = c; q0 <= last; q0 += 64) {   // pieces of at most 64 slots: one wave-load each
-              t_seg_col[t].push_back((int32_t)(clo + q0));
-              t_seg_off[t].push_back(W + (int32_t)(q0 - c));
-              ++nseg;
-            }
-            for (int64_t q = c; q <= last; ++q) pos[q] = W++;
-            c = last + 1;
-          }
-          if (W > maxW || W > 4096) { bad = true; break; }
-          pl.blkW[b] = W;
-          blk_nseg[b] = nseg;
+          vs_window(rows, rp, col, GAP, maxW, w, &t_seg_col[t], &t_seg_off[t]);
+          pl.blkW[b] = w.W;
+          blk_nseg[b] = w.nseg;
           // dictionary (<= kVsMaxDict bit patterns) and the batch-major stream
           std::fill(ids.begin(), ids.end(), (int16_t)-1);
           const size_t d0 = t_dict[t].size();
           uint8_t *sp = pl.stream.data() + pl.sb[b];
-          uint32_t eoff = 0;  // padded entry offset inside the block
-          auto code_of = [&](double value) -> int {   // dictionary code of a value (-1: too many patterns)
+          uint32_t eoff = 0;  // 16-byte units from the block's first byte
+          auto field_of = [&](int64_t k) -> int64_t {   // (code << 15) | (window slot << 3) of CSR entry k; -1: dictionary full
             uint64_t bits;
-            std::memcpy(&bits, &value, 8);
+            std::memcpy(&bits, &val[k], 8);
             uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
             for (;;) {
               if (ids[h] < 0) {
                 if (t_dict[t].size() - d0 == (size_t)kVsMaxDict) return -1;
                 keys[h] = bits;
                 ids[h] = (int16_t)(t_dict[t].size() - d0);
-                t_dict[t].push_back(value);
-                return ids[h];
+                t_dict[t].push_back(val[k]);
+                break;
               }
-              if (keys[h] == bits) return ids[h];
+              if (keys[h] == bits) break;
               h = (h + 1) & (kTab - 1);
             }
+            return ((int64_t)ids[h] << 15) | ((int64_t)w.pos[col[k] - w.clo] << 3);
           };
           for (size_t q = 0; q < bts.size() && !bad; ++q) {
             const VsBatch &bt = bts[q];
-            uint8_t *fb = sp + 3 * (size_t)eoff;
+            uint8_t *fb = sp + 16 * (size_t)eoff;
             uint64_t *dst = &pl.tab[((size_t)b * maxb + q) * 4];
             for (int i = 0; i < 4 && !bad; ++i) {
               const int src = i < bt.nreal ? i : 0;     // fillers repeat the batch's first row
               const int32_t r = rows[bt.id[src]];
-              const int64_t k0 = rp[r], n = len[bt.id[src]];
-              for (int64_t k = 0; k < n; ++k) {   // entry k: chunk k / 64, lane k % 64, row slot i
-                uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64);
-                const int cd = code_of(val[k0 + k]);
-                if (cd < 0) { bad = true; break; }
-                const uint32_t f = ((uint32_t)cd << 15) | ((uint32_t)pos[col[k0 + k] - clo] << 3);
-                cell[3 * i] = (uint8_t)f;   // row slot i: bytes 3i .. 3i+2 of the 12-byte cell
-                cell[3 * i + 1] = (uint8_t)(f >> 8);
-                cell[3 * i + 2] = (uint8_t)(f >> 16);
-              }
-              dst[i] = (uint64_t)eoff | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) |
+              const int64_t k0 = rp[r], n = rp[r + 1] - k0;
+              if (!bt.shared || i == 0)
+                for (int64_t k = 0; k < n; ++k) {   // entry k: chunk k / 64, lane k % 64 (row slot i of a plain batch)
+                  const int64_t f = field_of(k0 + k);
+                  if (f < 0) { bad = true; break; }
+                  if (bt.shared) {
+                    const uint32_t f32 = (uint32_t)f;
+                    std::memcpy(fb + 256 * (size_t)(k / 64) + 4 * (size_t)(k % 64), &f32, 4);
+                  } else {
+                    uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64) + 3 * i;
+                    cell[0] = (uint8_t)f;
+                    cell[1] = (uint8_t)(f >> 8);
+                    cell[2] = (uint8_t)(f >> 16);
+                  }
+                }
+              // low 20 bits: the batch's offset; rows 1..3 of a shared batch: their window shift in bytes + 2^19
+              const uint64_t low = (bt.shared && i > 0) ? (uint64_t)((i < bt.nreal ? bt.shift[i] * 8 : 0) + (1 << 19)) : eoff;
+              dst[i] = low | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) |
                        ((uint64_t)(i < bt.nreal ? (uint32_t)r : 0xffffffffu) << 32);
             }
-            eoff += (uint32_t)vs_batch_units(bt, len.data());
+            if (bt.shared) dst[0] |= 1ull << 63;
+            eoff += (uint32_t)vs_batch_units(bt, rows, rp);
           }
           pl.dn[b] = (int32_t)(t_dict[t].size() - d0);
         }
@@ -2233,15 +2315,19 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
   v.nseg = (int64_t)pl.seg_col.size();
   v.stream_bytes = (int64_t)pl.stream.size() - 4096;
   v.nbatch = pl.nbatch;
+  v.shared_nnz = pl.shared_nnz;
   v.dict_total = (int64_t)pl.dict.size();
   v.stride = pl.stride;
   v.maxW = pl.maxW;
   v.bricks = hint;
   v.on = true;
   if (ctx->cfg.log_level > 0)
-    std::fprintf(stderr, "[alfd] batch-major format: %lld blocks (%s), %lld batches, window <= %d slots, %.2f B/nnz\n",
-                 (long long)pl.nb, hint ? "caller's row blocks" : "runs of the numbering", (long long)pl.nbatch,
-                 pl.maxW, (double)v.stream_bytes / (double)std::max<int64_t>(m.nnz, 1));
+    std::fprintf(stderr,
+                 "[alfd] batch-major format: %lld blocks (%s), %lld batches, window <= %d slots, %.2f B/nnz, %.1f %% of the "
+                 "entries in template-shared batches\n",
+                 (long long)pl.nb, hint ? "caller's row blocks" : "runs of the numbering", (long long)pl.nbatch, pl.maxW,
+                 (double)v.stream_bytes / (double)std::max<int64_t>(m.nnz, 1),
+                 100.0 * (double)pl.shared_nnz / (double)std::max<int64_t>(m.nnz, 1));
   return ALFD_OK;
 }
 
@@ -4206,6 +4292,7 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
   out->segments = (int64_t)pl.seg_col.size();
   out->dictionary_entries = (int64_t)pl.dict.size();
   out->stream_bytes = (int64_t)pl.stream.size() - 4096;
+  out->shared_nnz = pl.shared_nnz;
   std::vector<uint8_t> seen(nrows, 0);
   int64_t bad = 0, covered = 0;
   std::vector<int32_t> slot_col;
@@ -4224,24 +4311,34 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
       auto off = [](uint64_t dd) { return (uint32_t)dd & 0xfffffu; };
       auto cnt_of = [](uint64_t dd) { return ((uint32_t)dd >> 20) & 0x1ffu; };
       const uint32_t eb = off(dsc[0]);
-      if (eb % 16) ++bad;
+      const bool shared = (dsc[0] >> 63) != 0;
       const int cls = (int)(((uint32_t)dsc[0] >> 29) & 7u);
-      const uint8_t *fb = sp + 3 * (size_t)eb;
+      const uint8_t *fb = sp + 16 * (size_t)eb;
       for (int i = 0; i < 4; ++i) {
-        const int64_t r = (int32_t)(dsc[i] >> 32);
+        const uint32_t rfield = (uint32_t)(dsc[i] >> 32) & (i == 0 ? 0x7fffffffu : 0xffffffffu);
+        const int64_t r = (int32_t)rfield;
         if (r < 0) continue;  // filler
         if (r >= nrows || seen[r]) { ++bad; continue; }
         seen[r] = 1;
         ++covered;
         const uint32_t n = cnt_of(dsc[i]);
-        if (off(dsc[i]) != eb || (int64_t)n != rp[r + 1] - rp[r] || (int)((n + 63) / 64) != cls) { ++bad; continue; }
+        if ((int64_t)n != rp[r + 1] - rp[r] || (int)((n + 63) / 64) != cls) { ++bad; continue; }
+        if (shared ? n != cnt_of(dsc[0]) : off(dsc[i]) != eb) { ++bad; continue; }
+        const int32_t shift = (shared && i > 0) ? (int32_t)off(dsc[i]) - (1 << 19) : 0;   // bytes
+        if (shift % 8) ++bad;
         for (uint32_t k = 0; k < n; ++k) {
-          const uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64);
-          const uint32_t f = cell[3 * i] | ((uint32_t)cell[3 * i + 1] << 8) | ((uint32_t)cell[3 * i + 2] << 16);
-          const uint32_t lcv = (f >> 3) & 0xfffu, vcv = f >> 15;
-          if (f & 7u) ++bad;
+          uint32_t f;
+          if (shared) {
+            std::memcpy(&f, fb + 256 * (size_t)(k / 64) + 4 * (size_t)(k % 64), 4);
+          } else {
+            const uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64) + 3 * i;
+            f = cell[0] | ((uint32_t)cell[1] << 8) | ((uint32_t)cell[2] << 16);
+          }
+          if ((f & 7u) || (f >> 24)) ++bad;
+          const int32_t lcv = (int32_t)((f >> 3) & 0xfffu) + shift / 8;
+          const uint32_t vcv = f >> 15;
           const double v = (int32_t)vcv < pl.dn[b] ? pl.dict[pl.doff[b] + vcv] : std::nan("");
-          const int32_t c = (int32_t)lcv < pl.blkW[b] ? slot_col[lcv] : -1;
+          const int32_t c = (lcv >= 0 && lcv < pl.blkW[b]) ? slot_col[lcv] : -1;
           if (c != col[rp[r] + k] || std::memcmp(&v, &val[rp[r] + k], 8) != 0) ++bad;
         }
       }

@@ -35,8 +35,9 @@ constexpr int kVsMaxRows = 250;   // rows per block
 constexpr int kVsMaxLen = 384;    // longest row the format takes (class 6)
 
 // batch descriptor, one uint64 per row: eb (20 bits) | entry count (9) | class = ceil(count / 64) (3)
-// | global row, 0xffffffff = filler (32).  eb: the batch's offset from the block's first entry in
-// 3-byte units (a multiple of 16: the batch starts at byte 3 eb).  Fillers repeat row 0.
+// | global row, 0xffffffff = filler (32).  eb: the batch's offset from the block's first byte in 16-byte
+// units.  Fillers repeat row 0.  Bit 63 of row 0 marks a SHARED batch (vs_shared); there the low 20 bits
+// of rows 1..3 hold the row's window shift in bytes + 2^19 instead of eb.
 __device__ __forceinline__ uint32_t vs_off(uint64_t d) { return (uint32_t)d & 0xfffffu; }
 __device__ __forceinline__ int32_t vs_len(uint64_t d) { return (int32_t)(((uint32_t)d >> 20) & 0x1ffu); }
 __device__ __forceinline__ int vs_cls(uint64_t d) { return (int)(((uint32_t)d >> 29) & 7u); }
@@ -85,6 +86,38 @@ __device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem
         if (lane < rem[i]) acc[i] = fma(v[i], xv[i], acc[i]);
       } else {
         acc[i] = fma(v[i], xv[i], acc[i]);
+      }
+    }
+  }
+}
+
+// A SHARED batch: its rows are translates of one another (same length, same values entry by entry, window
+// columns differing by one constant per row) -- the rows of one node type inside a mesh brick.  One row
+// is stored (a dword per lane and chunk, lane-major), rows 1..3 add their window shift sh[i] (bytes):
+// a quarter of the stream, one dictionary gather instead of four.
+template <int NCH>
+__device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[4], int lane,
+                                          const uint8_t *__restrict__ fb, double (&acc)[4]) {
+  uint32_t w[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH - 1; ++j) w[j] = *(const uint32_t *)(fb + 256 * j + 4 * lane);
+  w[NCH - 1] = *(const uint32_t *)(fb + 256 * (NCH - 1) + 4 * (lane < rem ? lane : rem - 1));
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const uint32_t lc = w[j] & 0x7ff8u;
+    double v = vs_lds_f64(kVsDictOff + ((w[j] >> 12) & 0xff8u));
+    double xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xv[i] = vs_lds_f64(kVsWinOff + (uint32_t)((int32_t)lc + sh[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[i]));
+    asm volatile("" : "+v"(v));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (j == NCH - 1) {
+        if (lane < rem) acc[i] = fma(v, xv[i], acc[i]);
+      } else {
+        acc[i] = fma(v, xv[i], acc[i]);
       }
     }
   }
@@ -157,27 +190,41 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint32_t eb = vs_off(desc[0]);
     const int cls = vs_cls(desc[0]);
     const int32_t full = cls > 0 ? 64 * (cls - 1) : 0;
-    int32_t rem[4], maxrem = 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      rem[i] = vs_len(desc[i]) - full;
-      maxrem = rem[i] > maxrem ? rem[i] : maxrem;
-    }
-    const uint8_t *fb = sbase + 3u * (size_t)eb;
+    const uint8_t *fb = sbase + 16u * (size_t)eb;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    switch (cls) {
-      case 1: vs_batch<1>(rem, maxrem, lane, fb, sm, acc); break;
-      case 2: vs_batch<2>(rem, maxrem, lane, fb, sm, acc); break;
-      case 3: vs_batch<3>(rem, maxrem, lane, fb, sm, acc); break;
-      case 4: vs_batch<4>(rem, maxrem, lane, fb, sm, acc); break;
-      case 5: vs_batch<5>(rem, maxrem, lane, fb, sm, acc); break;
-      case 6: vs_batch<6>(rem, maxrem, lane, fb, sm, acc); break;
-      default: break;  // class 0: empty rows
+    if ((int64_t)desc[0] < 0) {   // shared batch (wave-uniform)
+      const int32_t rem = vs_len(desc[0]) - full;
+      const int32_t sh[4] = {0, (int32_t)vs_off(desc[1]) - (1 << 19), (int32_t)vs_off(desc[2]) - (1 << 19),
+                             (int32_t)vs_off(desc[3]) - (1 << 19)};
+      switch (cls) {
+        case 1: vs_shared<1>(rem, sh, lane, fb, acc); break;
+        case 2: vs_shared<2>(rem, sh, lane, fb, acc); break;
+        case 3: vs_shared<3>(rem, sh, lane, fb, acc); break;
+        case 4: vs_shared<4>(rem, sh, lane, fb, acc); break;
+        case 5: vs_shared<5>(rem, sh, lane, fb, acc); break;
+        default: vs_shared<6>(rem, sh, lane, fb, acc); break;
+      }
+    } else {
+      int32_t rem[4], maxrem = 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rem[i] = vs_len(desc[i]) - full;
+        maxrem = rem[i] > maxrem ? rem[i] : maxrem;
+      }
+      switch (cls) {
+        case 1: vs_batch<1>(rem, maxrem, lane, fb, sm, acc); break;
+        case 2: vs_batch<2>(rem, maxrem, lane, fb, sm, acc); break;
+        case 3: vs_batch<3>(rem, maxrem, lane, fb, sm, acc); break;
+        case 4: vs_batch<4>(rem, maxrem, lane, fb, sm, acc); break;
+        case 5: vs_batch<5>(rem, maxrem, lane, fb, sm, acc); break;
+        case 6: vs_batch<6>(rem, maxrem, lane, fb, sm, acc); break;
+        default: break;  // class 0: empty rows
+      }
     }
     const double s = reduce_rows4(acc[0], acc[1], acc[2], acc[3]);
     const int q = lane >> 4;  // 16-lane row q holds the tree of batch row {0, 2, 1, 3}[q]
     const uint64_t dq = q == 0 ? desc[0] : (q == 1 ? desc[2] : (q == 2 ? desc[1] : desc[3]));
-    const int32_t r = (int32_t)(dq >> 32);
+    const int32_t r = q == 0 ? (int32_t)((dq >> 32) & 0x7fffffffu) : (int32_t)(dq >> 32);   // bit 63 of row 0: shared flag
     if ((lane & 15) == 0 && r >= 0) {
       if (EPI == 0)
         y[r] = s;

@@ -392,6 +392,7 @@ typedef struct alfd_stream_plan_info {
   int32_t ok, max_window, max_rows, max_batches;
   int64_t blocks, batches, segments, dictionary_entries, stream_bytes;
   int64_t decode_mismatches, rows_covered;
+  int64_t shared_nnz;   /* entries of rows stored as translates of a template row (one stored row per batch) */
 } alfd_stream_plan_info;
 int alfd_host_stream_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
                           int32_t row_block, int64_t n_blocks, const int64_t *block_ptr, const int32_t *rows,
