@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--cheb-degree", type=int, default=4)
     ap.add_argument("--inner-max", type=int, default=100,
                     help="cap of the inner CG: 100 = parameters_stokes_3d.prm:23 (the reference throws beyond it)")
-    ap.add_argument("--bricks", default="8,4,2",
+    ap.add_argument("--bricks", default="16,4,1",
                     help="row blocks of the A-SpMV: nodes of an a x b x c patch of the velocity grid (0 = runs of the numbering)")
     ap.add_argument("--general-steps", type=int, default=1,
                     help="extra timed solves with the dictionary-free 10 B/nnz SpMV kernel (0 = skip)")

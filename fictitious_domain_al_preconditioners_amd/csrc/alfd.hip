@@ -111,7 +111,7 @@ struct DevCsr {
   double streamed_bytes(bool use_vi, bool use_vs = false) const {
     const double vec = (double)(n_list + 1) * 8.0 + (double)n_list * 8.0 + (double)(sparse ? n_list : ncols) * 8.0;
     if (vs.on && use_vs && use_vi)
-      return (double)vs.stream_bytes + 32.0 * (double)vs.nbatch + 28.0 * (double)vs.nb +
+      return (double)vs.stream_bytes + 64.0 * (double)vs.nbatch + 28.0 * (double)vs.nb +
              8.0 * (double)vs.nseg + 8.0 * (double)vs.dict_total + 8.0 * (double)nrows +
              8.0 * (double)(sparse ? n_list : ncols);
     if (!win) return (double)nnz * 12.0 + vec;
@@ -1907,9 +1907,9 @@ struct VsPlan {
 };
 
 struct VsBatch {
-  int cls, nreal, id[4];
-  bool shared;        // the rows are translates of one another: one template + a window shift per row
-  int32_t shift[4];   // window slots, relative to row id[0]
+  int cls, nreal, id[8];   // plain: up to 4 rows; shared: up to 8
+  bool shared;             // the rows are translates of one another: one template + a window shift per row
+  int32_t shift[8];        // window slots, relative to row id[0]
 };
 
 // x window of a row block: maximal runs of used columns, gaps shorter than GAP bridged, cut into pieces
@@ -2012,14 +2012,17 @@ static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, cons
         size_t g1 = g0 + 1;
         while (g1 < ids.size() && key[ids[g1]] == key[ids[g0]] && same(ids[g0], ids[g1])) ++g1;
         size_t q = g0;
-        for (; q + 2 <= g1; q += 4) {   // 2..4 rows per shared batch
-          VsBatch bt{cls, 0, {0, 0, 0, 0}, true, {0, 0, 0, 0}};
-          for (size_t i = q; i < std::min(q + 4, g1); ++i) {
+        while (g1 - q >= 2) {   // 2..8 rows per shared batch (never a lone leftover if it can be avoided)
+          const size_t left = g1 - q;
+          const size_t take = left == 9 ? 5 : std::min<size_t>(8, left);
+          VsBatch bt{cls, 0, {0, 0, 0, 0, 0, 0, 0, 0}, true, {0, 0, 0, 0, 0, 0, 0, 0}};
+          for (size_t i = q; i < q + take; ++i) {
             bt.id[bt.nreal] = ids[i];
             bt.shift[bt.nreal] = first[ids[i]] - first[ids[q]];
             ++bt.nreal;
           }
           out.push_back(bt);
+          q += take;
         }
         for (; q < g1; ++q) plain.push_back(ids[q]);
         g0 = g1;
@@ -2028,7 +2031,7 @@ static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, cons
     // plain batches: longest first, so that the rows of a batch have equal or close remainders in the last chunk
     std::stable_sort(plain.begin(), plain.end(), [&](int a, int b) { return len[a] != len[b] ? len[a] > len[b] : a < b; });
     for (size_t q = 0; q < plain.size(); q += 4) {
-      VsBatch bt{cls, 0, {0, 0, 0, 0}, false, {0, 0, 0, 0}};
+      VsBatch bt{cls, 0, {0, 0, 0, 0, 0, 0, 0, 0}, false, {0, 0, 0, 0, 0, 0, 0, 0}};
       for (size_t i = q; i < std::min(q + 4, plain.size()); ++i) bt.id[bt.nreal++] = plain[i];
       out.push_back(bt);
     }
@@ -2178,7 +2181,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
   pl.stride = maxb;
   pl.rbs = maxr;
   pl.stream.assign((size_t)tot + 4096, 0);
-  pl.tab.assign((size_t)nb * maxb * 4, 0);
+  pl.tab.assign((size_t)nb * maxb * 8, 0);
   pl.cnt.assign(nb, 0);
   pl.blkW.assign(nb, 0);
   pl.dn.assign(nb, 0);
@@ -2227,12 +2230,12 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
           for (size_t q = 0; q < bts.size() && !bad; ++q) {
             const VsBatch &bt = bts[q];
             uint8_t *fb = sp + 16 * (size_t)eoff;
-            uint64_t *dst = &pl.tab[((size_t)b * maxb + q) * 4];
-            for (int i = 0; i < 4 && !bad; ++i) {
+            uint64_t *dst = &pl.tab[((size_t)b * maxb + q) * 8];
+            for (int i = 0; i < 8 && !bad; ++i) {
               const int src = i < bt.nreal ? i : 0;     // fillers repeat the batch's first row
               const int32_t r = rows[bt.id[src]];
               const int64_t k0 = rp[r], n = rp[r + 1] - k0;
-              if (!bt.shared || i == 0)
+              if (bt.shared ? i == 0 : i < 4)
                 for (int64_t k = 0; k < n; ++k) {   // entry k: chunk k / 64, lane k % 64 (row slot i of a plain batch)
                   const int64_t f = field_of(k0 + k);
                   if (f < 0) { bad = true; break; }
@@ -2246,7 +2249,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
                     cell[2] = (uint8_t)(f >> 16);
                   }
                 }
-              // low 20 bits: the batch's offset; rows 1..3 of a shared batch: their window shift in bytes + 2^19
+              // low 20 bits: the batch's offset; rows 1.. of a shared batch: their window shift in bytes + 2^19
               const uint64_t low = (bt.shared && i > 0) ? (uint64_t)((i < bt.nreal ? bt.shift[i] * 8 : 0) + (1 << 19)) : eoff;
               dst[i] = low | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) |
                        ((uint64_t)(i < bt.nreal ? (uint32_t)r : 0xffffffffu) << 32);
@@ -4307,15 +4310,16 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
     const uint8_t *sp = pl.stream.data() + pl.sb[b];
     if (pl.sb[b] % 16) ++bad;
     for (int q = 0; q < nbt; ++q) {
-      const uint64_t *dsc = &pl.tab[((size_t)b * pl.stride + q) * 4];
+      const uint64_t *dsc = &pl.tab[((size_t)b * pl.stride + q) * 8];
       auto off = [](uint64_t dd) { return (uint32_t)dd & 0xfffffu; };
       auto cnt_of = [](uint64_t dd) { return ((uint32_t)dd >> 20) & 0x1ffu; };
       const uint32_t eb = off(dsc[0]);
       const bool shared = (dsc[0] >> 63) != 0;
       const int cls = (int)(((uint32_t)dsc[0] >> 29) & 7u);
       const uint8_t *fb = sp + 16 * (size_t)eb;
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
         const uint32_t rfield = (uint32_t)(dsc[i] >> 32) & (i == 0 ? 0x7fffffffu : 0xffffffffu);
+        if (!shared && i >= 4 && (int32_t)rfield >= 0) ++bad;   // plain batches hold 4 rows
         const int64_t r = (int32_t)rfield;
         if (r < 0) continue;  // filler
         if (r >= nrows || seen[r]) { ++bad; continue; }

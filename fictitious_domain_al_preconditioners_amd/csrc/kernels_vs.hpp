@@ -34,10 +34,10 @@ constexpr int kVsWinOff = kVsMaxDict * 8;   // the x window behind it (at most 4
 constexpr int kVsMaxRows = 250;   // rows per block
 constexpr int kVsMaxLen = 384;    // longest row the format takes (class 6)
 
-// batch descriptor, one uint64 per row: eb (20 bits) | entry count (9) | class = ceil(count / 64) (3)
+// batch descriptor: 8 x uint64, one per row: eb (20 bits) | entry count (9) | class = ceil(count / 64) (3)
 // | global row, 0xffffffff = filler (32).  eb: the batch's offset from the block's first byte in 16-byte
-// units.  Fillers repeat row 0.  Bit 63 of row 0 marks a SHARED batch (vs_shared); there the low 20 bits
-// of rows 1..3 hold the row's window shift in bytes + 2^19 instead of eb.
+// units.  Plain batches use rows 0..3 (fillers repeat row 0).  Bit 63 of row 0 marks a SHARED batch
+// (vs_shared) of up to 8 rows; there the low 20 bits of rows 1.. hold the row's window shift in bytes + 2^19.
 __device__ __forceinline__ uint32_t vs_off(uint64_t d) { return (uint32_t)d & 0xfffffu; }
 __device__ __forceinline__ int32_t vs_len(uint64_t d) { return (int32_t)(((uint32_t)d >> 20) & 0x1ffu); }
 __device__ __forceinline__ int vs_cls(uint64_t d) { return (int)(((uint32_t)d >> 29) & 7u); }
@@ -91,13 +91,13 @@ __device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem
   }
 }
 
-// A SHARED batch: its rows are translates of one another (same length, same values entry by entry, window
-// columns differing by one constant per row) -- the rows of one node type inside a mesh brick.  One row
-// is stored (a dword per lane and chunk, lane-major), rows 1..3 add their window shift sh[i] (bytes):
-// a quarter of the stream, one dictionary gather instead of four.
-template <int NCH>
-__device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[4], int lane,
-                                          const uint8_t *__restrict__ fb, double (&acc)[4]) {
+// A SHARED batch: its R = 4 or 8 rows are translates of one another (same length, same values entry by
+// entry, window columns differing by one constant per row) -- the rows of one node type inside a mesh
+// brick.  One row is stored (a dword per lane and chunk, lane-major), the others add their window shift
+// sh[i] (bytes): 1/R of the stream, one dictionary gather instead of R.
+template <int NCH, int R>
+__device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[R], int lane,
+                                          const uint8_t *__restrict__ fb, double (&acc)[R]) {
   uint32_t w[NCH];
 #pragma unroll
   for (int j = 0; j < NCH - 1; ++j) w[j] = *(const uint32_t *)(fb + 256 * j + 4 * lane);
@@ -106,19 +106,21 @@ __device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[4], i
   for (int j = 0; j < NCH; ++j) {
     const uint32_t lc = w[j] & 0x7ff8u;
     double v = vs_lds_f64(kVsDictOff + ((w[j] >> 12) & 0xff8u));
-    double xv[4];
+    double xv[R];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xv[i] = vs_lds_f64(kVsWinOff + (uint32_t)((int32_t)lc + sh[i]));
+    for (int i = 0; i < R; ++i) xv[i] = vs_lds_f64(kVsWinOff + (uint32_t)((int32_t)lc + sh[i]));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xv[i]));
+    for (int i = 0; i < R; ++i) asm volatile("" : "+v"(xv[i]));
     asm volatile("" : "+v"(v));
+    if (j == NCH - 1) {
+      if (lane < rem) {   // one exec mask around the fmas (the empty asm keeps it a branch, not 2 R selects)
+        asm volatile("");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (j == NCH - 1) {
-        if (lane < rem) acc[i] = fma(v, xv[i], acc[i]);
-      } else {
-        acc[i] = fma(v, xv[i], acc[i]);
+        for (int i = 0; i < R; ++i) acc[i] = fma(v, xv[i], acc[i]);
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < R; ++i) acc[i] = fma(v, xv[i], acc[i]);
     }
   }
 }
@@ -145,11 +147,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   }
   const int32_t nbatch = cnt[b];
   const uint8_t *sbase = stream + sb[b];
-  const uint64_t *bt = tab + ((int64_t)b * stride + wave) * 4;
-  uint64_t nx[4] = {0, 0, 0, 0};
+  const uint64_t *bt = tab + ((int64_t)b * stride + wave) * 8;
+  uint64_t nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (wave < nbatch) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nx[i] = bt[i];
+    for (int i = 0; i < 8; ++i) nx[i] = bt[i];
   }
   {  // block frame: dictionary and x window (segments of at most 64 slots, 4 in flight per wave)
     const int32_t nd = blk_dict_n[b];
@@ -178,31 +180,69 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
   }
   __syncthreads();
+  auto store4 = [&](double s, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3) {
+    const int q = lane >> 4;  // 16-lane row q holds the tree of batch row {0, 2, 1, 3}[q]
+    const uint64_t dq = q == 0 ? d0 : (q == 1 ? d2 : (q == 2 ? d1 : d3));
+    const int32_t r = (int32_t)(dq >> 32);
+    if ((lane & 15) == 0 && r >= 0) {
+      if (EPI == 0)
+        y[r] = s;
+      else if (EPI == 1)
+        y[r] = fma(alpha, s, y[r]);
+      else if (EPI == 2)
+        y[r] = d[r] * s;
+      else {
+        y[r] = s;
+        y2[r] = d[r] * s;
+      }
+    }
+  };
   for (int32_t bi = wave; bi < nbatch; bi += NW) {
-    uint64_t desc[4];
+    uint64_t desc[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) desc[i] = nx[i];
-    bt += 4 * NW;
-    if (bi + NW < nbatch) {  // next descriptor: one s_load_dwordx8, in flight during this batch
+    for (int i = 0; i < 8; ++i) desc[i] = nx[i];
+    bt += 8 * NW;
+    if (bi + NW < nbatch) {  // next descriptor: one s_load_dwordx16, in flight during this batch
 #pragma unroll
-      for (int i = 0; i < 4; ++i) nx[i] = bt[i];
+      for (int i = 0; i < 8; ++i) nx[i] = bt[i];
     }
     const uint32_t eb = vs_off(desc[0]);
     const int cls = vs_cls(desc[0]);
     const int32_t full = cls > 0 ? 64 * (cls - 1) : 0;
     const uint8_t *fb = sbase + 16u * (size_t)eb;
+    const bool shared = (int64_t)desc[0] < 0;           // wave-uniform
+    desc[0] &= 0x7fffffffffffffffull;                    // bit 63 was the flag, not part of the row
+    if (shared && (int32_t)(desc[4] >> 32) >= 0) {       // 5..8 translates
+      const int32_t rem = vs_len(desc[0]) - full;
+      int32_t sh[8];
+      sh[0] = 0;
+#pragma unroll
+      for (int i = 1; i < 8; ++i) sh[i] = (int32_t)vs_off(desc[i]) - (1 << 19);
+      double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      switch (cls) {
+        case 1: vs_shared<1, 8>(rem, sh, lane, fb, acc); break;
+        case 2: vs_shared<2, 8>(rem, sh, lane, fb, acc); break;
+        case 3: vs_shared<3, 8>(rem, sh, lane, fb, acc); break;
+        case 4: vs_shared<4, 8>(rem, sh, lane, fb, acc); break;
+        case 5: vs_shared<5, 8>(rem, sh, lane, fb, acc); break;
+        default: vs_shared<6, 8>(rem, sh, lane, fb, acc); break;
+      }
+      store4(reduce_rows4(acc[0], acc[1], acc[2], acc[3]), desc[0], desc[1], desc[2], desc[3]);
+      store4(reduce_rows4(acc[4], acc[5], acc[6], acc[7]), desc[4], desc[5], desc[6], desc[7]);
+      continue;
+    }
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if ((int64_t)desc[0] < 0) {   // shared batch (wave-uniform)
+    if (shared) {   // 2..4 translates
       const int32_t rem = vs_len(desc[0]) - full;
       const int32_t sh[4] = {0, (int32_t)vs_off(desc[1]) - (1 << 19), (int32_t)vs_off(desc[2]) - (1 << 19),
                              (int32_t)vs_off(desc[3]) - (1 << 19)};
       switch (cls) {
-        case 1: vs_shared<1>(rem, sh, lane, fb, acc); break;
-        case 2: vs_shared<2>(rem, sh, lane, fb, acc); break;
-        case 3: vs_shared<3>(rem, sh, lane, fb, acc); break;
-        case 4: vs_shared<4>(rem, sh, lane, fb, acc); break;
-        case 5: vs_shared<5>(rem, sh, lane, fb, acc); break;
-        default: vs_shared<6>(rem, sh, lane, fb, acc); break;
+        case 1: vs_shared<1, 4>(rem, sh, lane, fb, acc); break;
+        case 2: vs_shared<2, 4>(rem, sh, lane, fb, acc); break;
+        case 3: vs_shared<3, 4>(rem, sh, lane, fb, acc); break;
+        case 4: vs_shared<4, 4>(rem, sh, lane, fb, acc); break;
+        case 5: vs_shared<5, 4>(rem, sh, lane, fb, acc); break;
+        default: vs_shared<6, 4>(rem, sh, lane, fb, acc); break;
       }
     } else {
       int32_t rem[4], maxrem = 1;
@@ -221,22 +261,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         default: break;  // class 0: empty rows
       }
     }
-    const double s = reduce_rows4(acc[0], acc[1], acc[2], acc[3]);
-    const int q = lane >> 4;  // 16-lane row q holds the tree of batch row {0, 2, 1, 3}[q]
-    const uint64_t dq = q == 0 ? desc[0] : (q == 1 ? desc[2] : (q == 2 ? desc[1] : desc[3]));
-    const int32_t r = q == 0 ? (int32_t)((dq >> 32) & 0x7fffffffu) : (int32_t)(dq >> 32);   // bit 63 of row 0: shared flag
-    if ((lane & 15) == 0 && r >= 0) {
-      if (EPI == 0)
-        y[r] = s;
-      else if (EPI == 1)
-        y[r] = fma(alpha, s, y[r]);
-      else if (EPI == 2)
-        y[r] = d[r] * s;
-      else {
-        y[r] = s;
-        y2[r] = d[r] * s;
-      }
-    }
+    store4(reduce_rows4(acc[0], acc[1], acc[2], acc[3]), desc[0], desc[1], desc[2], desc[3]);
   }
 }
 

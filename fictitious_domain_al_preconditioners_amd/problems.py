@@ -362,7 +362,7 @@ def row_support_points(params: dict, node_range=None):
     return np.repeat(pts, ncomp, axis=0)
 
 
-def brick_row_blocks(params: dict, brick=(8, 4, 2), max_rows: int = 250, node_range=None):
+def brick_row_blocks(params: dict, brick=(16, 4, 1), max_rows: int = 250, node_range=None):
     """Row blocks for Context.set_row_blocks (alfd_set_row_blocks) on the tensor-grid background space:
     the nodes of a brick[0] x brick[1] (x brick[2]) patch of the grid, all components of a node together
     (node-major, the numbering of the block-(0,0) operator).  node_range = (first, last+1) restricts the
