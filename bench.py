@@ -183,6 +183,24 @@ def main():
                 traffic = t.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # what else is loaded besides HBM (PMC counters of the same kernel, profiles/r02/pmc_vs.json): with 0.9 B/nnz the
+    # A-SpMV is bound by the vector ALU and the LDS gather rate, not by HBM -- reported next to the HBM figures
+    other_limits = None
+    ppath = os.path.join(ROOT, "profiles", "r02", "pmc_vs.json")
+    if traffic and os.path.exists(ppath) and avg_ms > 0:
+        try:
+            pm = json.load(open(ppath))["median"]
+            cycles = avg_ms * 1e-3 * 2.4e9                      # 2.4 GHz engine clock
+            other_limits = {
+                "source": "profiles/r02/pmc_vs.json (rocprofv3 --pmc, same kernel and matrix)",
+                "valu_issue_frac": pm["SQ_INSTS_VALU"] * 4.0 / (1024 * cycles),      # 4 cycles per wave64 VALU op, 1024 SIMDs
+                "lds_busy_frac": pm["SQ_LDS_IDX_ACTIVE"] / (256 * cycles),           # LDS pipe cycles per CU
+                "lds_gather_GBps": (info["nnz"] * 8.0 * 1.15) / (avg_ms * 1e-3) / 1e9,  # 8-byte window gather per entry + dictionary gathers
+                "lds_peak_GBps": 256 * 128 * 2.4,                                     # 128 B/clk/CU
+                "vmem_load_instructions": pm["SQ_INSTS_VMEM_RD"], "valu_instructions": pm["SQ_INSTS_VALU"],
+            }
+        except Exception:
+            other_limits = None
     # ---- the same solve with the dictionary-free kernel (what a matrix with unrelated values gets)
     general = None
     if world == 1 and info["value_indexed"] and args.general_steps > 0:
@@ -258,6 +276,7 @@ def main():
             "value_indexed_nnz_share": info["value_indexed_nnz"] / max(info["nnz"], 1),
             "launches": spmv["launches"],
             "time_share_spmv_A": spmv["ms"] * 1e-3 / dt,
+            "other_limits": other_limits,
         },
         # the whole solve again with the general-matrix SpMV kernel (no value dictionary anywhere):
         # the figure a matrix WITHOUT repeating entry values would get
