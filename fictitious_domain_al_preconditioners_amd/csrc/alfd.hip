@@ -3950,12 +3950,13 @@ int alfd_spmv(alfd_ctx_t ctx, int slot, const double *x, double *y, int mode, do
   CHECK_CTX();
   if (slot < 0 || slot >= ALFD_NSLOTS || !ctx->mat[slot].present) return ALFD_E_INVALID;
   if (!x || !y || (mode != 0 && mode != 1)) return ALFD_E_INVALID;
-  if (ctx->nranks > 1) return ctx->err = "alfd_spmv primitive is single-rank", ALFD_E_UNSUPPORTED;
   const DevCsr &m = ctx->mat[slot];
+  // partitioned context: collective over the ranks; x = this rank's owned columns, y = its rows
+  const int64_t nx = ctx->nranks > 1 ? (int64_t)m.n_local_cols : m.ncols;
   double *dx = nullptr, *dy = nullptr;
-  HIPC(hipMalloc((void **)&dx, std::max<int64_t>(m.ncols, 1) * sizeof(double)));
+  HIPC(hipMalloc((void **)&dx, std::max<int64_t>(nx, 1) * sizeof(double)));
   HIPC(hipMalloc((void **)&dy, std::max<int64_t>(m.nrows, 1) * sizeof(double)));
-  HIPC(hipMemcpyAsync(dx, x, m.ncols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(dx, x, nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   HIPC(hipMemcpyAsync(dy, y, m.nrows * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   const int rc = spmv(ctx, slot, dx, dy, mode, alpha);
   if (rc == ALFD_OK) {

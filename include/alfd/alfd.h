@@ -346,7 +346,8 @@ int alfd_get_history(alfd_ctx_t ctx, double *out, int32_t capacity, int32_t *cou
 
 /* ------------------------------------------------------------- primitives
  * The kernels under the solver, callable on host data for parity tests
- * (SURVEY.md 8(a) a13/a14).  y = A x (mode 0) or y += alpha A x (mode 1). */
+ * (SURVEY.md 8(a) a13/a14).  y = A x (mode 0) or y += alpha A x (mode 1).  On a partitioned context
+ * alfd_spmv is collective: x holds this rank's owned columns of the slot's column block, y its rows. */
 int alfd_spmv(alfd_ctx_t ctx, int slot, const double *x, double *y, int mode, double alpha);
 int alfd_dot(alfd_ctx_t ctx, int64_t n, const double *x, const double *y, double *result);
 /* Lanes per row the canonical SpMV order uses for this slot (after setup). */

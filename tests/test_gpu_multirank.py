@@ -96,6 +96,36 @@ def test_partitioned_matches_single_rank_to_rounding(built):
     assert np.allclose(out[0]["hist"], h1, rtol=1e-6)
 
 
+def test_partitioned_bench_like_solve_matches_single_rank(built):
+    """The bench configuration on two ranks at a size where the operators use the LDS-window / batch-major
+    formats (halo columns inside the staged windows, multigrid level matrices partitioned or replicated):
+    same iteration counts as the single-rank solve with the SAME slab-respecting aggregates, histories equal to
+    the rounding of the differently associated dot products."""
+    n, ref, world = 28, 1, 2
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    cfg.inner.max_steps = 100
+    cfg.inner_prec = _abi.PREC_MULTILEVEL
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+    full = problems.stokes3d_sphere(n, ref)
+    plan = partition.slab_partition_stokes3d(n, ref, world)
+    levels = partition.partitioned_geometric_aggregates(full.params, plan, a=2, min_coarse=600)
+    plan, out = _run_ranks(world, n, ref, cfg, levels)
+    ctx = solver.Context(0)
+    ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(full.params, (16, 4, 1)))
+    solver.upload_problem(ctx, full, cfg, [(a, nc) for a, nc, _, _ in levels])
+    assert ctx.matrix_info(_abi.A)["batch_major"] == 2
+    x, res = ctx.solve(ctx.augment_rhs(cases.rhs_of(full)))
+    h1 = ctx.history()
+    ctx.close()
+    for r in range(world):
+        assert out[r]["res"]["status"] == 0
+        assert (out[r]["res"]["outer_iterations"], out[r]["res"]["inner_iterations"]) == \
+            (res.outer_iterations, res.inner_iterations)
+        assert np.allclose(out[r]["hist"], h1, rtol=1e-6)
+    xs = np.concatenate([out[r]["x"][0] for r in range(world)])
+    assert np.allclose(xs, x[0], rtol=1e-6, atol=1e-8 * np.abs(x[0]).max())
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_partitioned_multilevel_solve_matches_oracle_emulation(built, world):
     """ALFD_PREC_MULTILEVEL on the row-partitioned path: slab-respecting aggregates,
@@ -206,6 +236,48 @@ def test_rank_without_multiplier_rows(built):
     for b in range(3):
         xs = np.concatenate([out[r]["x"][b] for r in range(world)])
         assert np.allclose(xs, ox[b], rtol=1e-9, atol=1e-10 * max(np.abs(ox[b]).max(), 1e-30))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_batch_major_spmv_bitwise(built, world):
+    """The A-SpMV of a partition large enough for the LDS-window / batch-major formats (>= 2048 row blocks per
+    rank; the solves above are too small for them): halo columns inside the staged x windows, mesh-brick row
+    blocks per rank.  Every rank's rows must equal the unpartitioned product bit for bit."""
+    n, ref = 28 + 8 * (world - 2), 0
+    plan = partition.slab_partition_stokes3d(n, ref, world)
+    full = problems.stokes3d_sphere(n, ref)
+    a = full.mats["A"]
+    x = np.random.default_rng(3).uniform(-1, 1, a.ncols)
+    want, _ = oracle.spmv(a, x, None, mode=0)
+    group = solver.LocalGroup(world)
+    out, fmt, errs = [None] * world, [None] * world, []
+    uoff = plan.offsets[0]
+
+    def work(rank):
+        try:
+            pb = problems.stokes3d_sphere(n, ref, row_ranges=plan.generator_ranges(rank))
+            ctx = solver.Context(0)
+            ctx.comm_init_local(group.handle, rank)
+            ctx.set_partition(plan.offsets)
+            ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(
+                pb.params, (16, 4, 1), node_range=(plan.node_offsets_u[rank], plan.node_offsets_u[rank + 1])))
+            ctx.set_matrix(_abi.A, pb.mats["A"])
+            fmt[rank] = ctx.matrix_info(_abi.A)
+            xl = x[uoff[rank]:uoff[rank + 1]]
+            out[rank], _ = ctx.spmv(_abi.A, xl, np.zeros(pb.mats["A"].nrows), mode=0)
+            ctx.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    group.close()
+    assert not errs, errs
+    assert all(f["windowed"] and f["batch_major"] == 2 for f in fmt), fmt
+    assert np.array_equal(np.concatenate(out), want)
 
 
 def _run_interface_ranks(world, plan, make_local, cfg):
