@@ -121,13 +121,14 @@ def main():
         levels = partition.partitioned_geometric_aggregates(pb.params, plan, a=args.agg_a, min_coarse=args.min_coarse)   # slab-respecting boxes
         aggregates = partition.local_aggregates(levels, rank)
         log(f"aggregates: levels {[lv[1] for lv in levels]} in {time.time()-ta:.1f} s")
+    row_blocks = None
     if args.bricks != "0":
         # row blocks of the A-SpMV = bricks of the Q2 grid inside this rank's slab (alfd_set_row_blocks):
         # a third of the x window that 96 consecutive rows of the lexicographic numbering need
         brick = tuple(int(v) for v in args.bricks.split(","))
-        ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(
-            pb.params, brick, node_range=(int(plan.node_offsets_u[rank]), int(plan.node_offsets_u[rank + 1]))))
-    solver.upload_problem(ctx, pb, cfg, aggregates)
+        row_blocks = problems.brick_row_blocks(
+            pb.params, brick, node_range=(int(plan.node_offsets_u[rank]), int(plan.node_offsets_u[rank + 1])))
+    solver.upload_problem(ctx, pb, cfg, aggregates, row_blocks)
     rhs = ctx.augment_rhs([pb.vecs["f"], pb.vecs["rhs_p"], pb.vecs["g"]])
     ctx.upload_rhs(rhs)
     log(f"uploaded + setup in {time.time()-t0:.1f} s")

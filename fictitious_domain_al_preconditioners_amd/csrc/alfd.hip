@@ -4186,14 +4186,30 @@ struct Rcb {
     int ax = 0;
     for (int d = 1; d < dim; ++d)
       if ((hi[d] - lo[d]) * weight[d] > (hi[ax] - lo[ax]) * weight[ax]) ax = d;
-    // cut so that the left part holds a multiple of max_rows/2 rows when possible (fewer ragged leaves)
-    const int64_t mid = a + (e - a) / 2;
-    std::nth_element(idx.begin() + a, idx.begin() + mid, idx.begin() + e, [&](int32_t p, int32_t q) {
-      const double cp = xyz[(int64_t)p * dim + ax], cq = xyz[(int64_t)q * dim + ax];
-      return cp < cq || (cp == cq && p < q);
-    });
+    const int64_t mid = cut(a, e, ax);
     split(a, mid, out);
     split(mid, e, out);
+  }
+  // Cut [a, e) along axis ax at a coordinate PLANE near the median: every point below the plane goes left, so
+  // that leaves are whole boxes of the mesh (their x windows are regular, which is what lets translate rows
+  // share a template).  Returns the split position.
+  int64_t cut(int64_t a, int64_t e, int ax) {
+    const int64_t mid = a + (e - a) / 2;
+    auto less = [&](int32_t p, int32_t q) {
+      const double cp = xyz[(int64_t)p * dim + ax], cq = xyz[(int64_t)q * dim + ax];
+      return cp < cq || (cp == cq && p < q);
+    };
+    std::nth_element(idx.begin() + a, idx.begin() + mid, idx.begin() + e, less);
+    const double cm = xyz[(int64_t)idx[mid] * dim + ax];
+    // points with coordinate == cm sit on both sides of mid: move the boundary to the nearer end of that plane
+    auto lo = std::partition(idx.begin() + a, idx.begin() + mid, [&](int32_t p) { return xyz[(int64_t)p * dim + ax] < cm; });
+    auto hi = std::partition(idx.begin() + mid, idx.begin() + e, [&](int32_t p) { return xyz[(int64_t)p * dim + ax] <= cm; });
+    const int64_t l = lo - idx.begin(), h = hi - idx.begin();   // [l, h) = the plane cm
+    int64_t pos = (mid - l <= h - mid) ? l : h;
+    if (pos == a) pos = h;
+    if (pos == e) pos = l;
+    if (pos == a || pos == e) pos = mid;   // a single plane (cannot happen: ax has a positive extent)
+    return pos;
   }
 };
 }  // namespace
@@ -4244,11 +4260,7 @@ int alfd_host_row_blocks_from_points(int64_t nrows, int32_t dim, const double *p
       int ax = 0;
       for (int d = 1; d < dim; ++d)
         if ((hi[d] - lo[d]) * r.weight[d] > (hi[ax] - lo[ax]) * r.weight[ax]) ax = d;
-      const int64_t mid = a + (e - a) / 2;
-      std::nth_element(r.idx.begin() + a, r.idx.begin() + mid, r.idx.begin() + e, [&](int32_t p, int32_t q) {
-        const double cp = points[(int64_t)p * dim + ax], cq = points[(int64_t)q * dim + ax];
-        return cp < cq || (cp == cq && p < q);
-      });
+      const int64_t mid = r.cut(a, e, ax);
       next.push_back({a, mid});
       next.push_back({mid, e});
     }

@@ -451,11 +451,14 @@ def host_stream_plan(m, row_block=96, blocks=None):
     return {k: getattr(info, k) for k, _ in info._fields_}
 
 
-def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None) -> Context:
+def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_blocks=None) -> Context:
     """Upload a problems.SyntheticProblem (whole, or this rank's rows) with the
     reference's diagonal choices: W^-1 = 1/M_ii^2 (stokes...:976-978), lumped
     pressure mass (stokes...:946-954).  aggregates: [(agg, n_coarse), ...] for
-    ALFD_PREC_MULTILEVEL (problems.geometric_aggregates)."""
+    ALFD_PREC_MULTILEVEL (problems.geometric_aggregates).  row_blocks: (block_ptr, rows)
+    for the SpMV on A (Context.set_row_blocks, e.g. problems.brick_row_blocks)."""
+    if row_blocks is not None:
+        ctx.set_row_blocks(_abi.A, *row_blocks)
     for level, entry in enumerate(aggregates or []):
         agg, nc = entry[0], entry[1]
         ctx.set_aggregates(level, agg, nc)
@@ -492,8 +495,8 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None) -> Conte
     return ctx
 
 
-def context_from_problem(pb, cfg: _abi.Config, device_id=0, aggregates=None) -> Context:
-    return upload_problem(Context(device_id), pb, cfg, aggregates)
+def context_from_problem(pb, cfg: _abi.Config, device_id=0, aggregates=None, row_blocks=None) -> Context:
+    return upload_problem(Context(device_id), pb, cfg, aggregates, row_blocks)
 
 
 # ---------------------------------------------------------------------------

@@ -426,7 +426,8 @@ def test_properties_at_bench_scale(built):
     cfg.inner.max_steps = 2000
     cfg.inner_prec = _abi.PREC_MULTILEVEL
     cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
-    ctx = solver.context_from_problem(pb, cfg, aggregates=problems.geometric_aggregates(pb, a=2))
+    ctx = solver.context_from_problem(pb, cfg, aggregates=problems.geometric_aggregates(pb, a=2),
+                                      row_blocks=problems.brick_row_blocks(pb.params, (16, 4, 1)))   # as bench.py
     rng = np.random.default_rng(0)
     xs = [[rng.uniform(-1, 1, n_) for n_ in pb.block_sizes] for _ in range(2)]
     a, b = 0.75, -1.25
@@ -462,12 +463,14 @@ def test_properties_at_bench_scale(built):
     ctx.close()
 
 
-def _full_size_properties(pb, cfg, rhs, aggs, outer_band, symmetric, augment, scipy_rows=None):
+def _full_size_properties(pb, cfg, rhs, aggs, outer_band, symmetric, augment, scipy_rows=None, row_blocks=None):
     """Size-independent checks on a full-size BASELINE config (no oracle at this size): linearity of the
     system operator, its symmetry where it is symmetric, the A-SpMV against SciPy, the true residual of
     the returned solution against the stop rule, bitwise repeatability, the outer-iteration band."""
-    ctx = solver.context_from_problem(pb, cfg, aggregates=aggs)
+    ctx = solver.context_from_problem(pb, cfg, aggregates=aggs, row_blocks=row_blocks)
     try:
+        if row_blocks is not None:
+            assert ctx.matrix_info(_abi.A)["batch_major"] == 2
         rng = np.random.default_rng(1)
         xs = [[rng.uniform(-1, 1, n_) for n_ in pb.block_sizes] for _ in range(2)]
         a, b = 0.75, -1.25
@@ -558,7 +561,8 @@ def test_properties_cfg5_full_size(built):
     aggs = problems.geometric_aggregates(pb, a=2, min_coarse=600)
     rhs = [pb.vecs["f"], pb.vecs["f2"], np.zeros(pb.block_sizes[2])]
     nr = pb.block_sizes[0]
-    res = _full_size_properties(pb, cfg, rhs, aggs, (12, 12), False, False, scipy_rows=(nr // 2, nr // 2 + 200000))
+    res = _full_size_properties(pb, cfg, rhs, aggs, (12, 12), False, False, scipy_rows=(nr // 2, nr // 2 + 200000),
+                                row_blocks=problems.brick_row_blocks(pb.params, (8, 4, 2)))
     print(f"cfg5 n={n}: outer {res.outer_iterations}, inner {res.inner_iterations}, {res.solve_seconds:.1f} s")
 
 
