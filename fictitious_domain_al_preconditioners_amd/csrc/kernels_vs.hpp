@@ -1,29 +1,31 @@
-// Batch-major value-indexed SpMV ("vs" format) for gfx950.
+// Batch-major value-indexed SpMV ("vs" format) for gfx950 -- the kernel the A-SpMV runs on.
 //
-// Same arithmetic as spmv_window_vib_kernel (canonical lane assignment, fma order and
-// 64-lane tree of ALFD-arith v1 -- bit-identical results); what differs is the storage:
+// Same arithmetic as spmv_window_vib_kernel (canonical lane assignment, fma order and 64-lane tree of
+// ALFD-arith v1 -- bit-identical results); what differs is the storage (planned on the host by plan_vs
+// in alfd.hip, decoded back by alfd_host_stream_plan for the CPU tests):
 //
-//  * a row block is an arbitrary LIST of rows, not a run of the numbering.  With blocks that
-//    are bricks of the mesh graph (alfd_set_row_blocks) the x window a block stages in LDS is
-//    a third of that of 96 consecutive rows of a lexicographic numbering (825 instead of
-//    2 700 slots at 96 rows): less L2 -> LDS staging, less HBM re-fetch of x, and 8 resident
-//    waves per SIMD instead of 4.9 (the window no longer limits occupancy);
-//  * the 3 B/nnz stream (12-bit window column + 9-bit dictionary code in 24 bits) is stored BATCH-MAJOR:
-//    the rows of a block are grouped by chunk count (and sorted by length) into batches of 4.
-//    A batch's 64-entry chunks are stored lane-major, the four rows interleaved (12 bytes
-//    per lane and chunk index: 4 x (12-bit window column + 9-bit code)), so one global_load_dwordx3
-//    replaces eight narrow loads; of the last, partial chunk only the lanes below the
-//    batch's longest remainder are stored.
-//    With the window small, the stream loads are what bounds the kernel (ablation: without
-//    them 0.61 ms, without the LDS gathers 1.29 of 1.30 ms), and a wave-level load costs the
-//    same ~8.5 issue cycles whether it carries 1 or 4 bytes per lane;
-//  * the 32-byte batch descriptor names the GLOBAL row of each of its 4 rows, so the four
-//    sums go straight to y.
+//  * a row block is a LIST of rows, not a run of the numbering.  With blocks that are bricks of the mesh
+//    (alfd_set_row_blocks / alfd_host_row_blocks_from_points) the x window a block stages in LDS is
+//    800..1 200 slots instead of 2 700 for 96 consecutive rows of a lexicographic numbering: a third of
+//    the L2 -> LDS staging and of the HBM re-fetch of x, 8 resident waves per SIMD instead of 4.9;
+//  * an entry is a 24-bit field, (9-bit dictionary code << 15) | (12-bit window column << 3): both LDS
+//    byte offsets ready-shifted.  Dictionaries hold up to 512 values per block (blocks beyond are halved);
+//  * the stream is BATCH-MAJOR and LANE-MAJOR: the rows of a block are grouped by chunk count
+//    ceil(len / 64) into batches; for chunk j, lane l finds what it needs at one address:
+//      - plain batch (4 rows): a 12-byte cell with the fields of the four rows at 768 j + 12 l -- one
+//        global_load_dwordx3 instead of eight 1- and 2-byte loads (a wave-level load costs ~8.5 issue
+//        cycles whether it carries 1 or 4 bytes per lane; with brick windows the stream loads were what
+//        bounded the kernel: ablation without them 0.61 ms, without the LDS gathers 1.29 of 1.30 ms);
+//      - shared batch (2..8 rows that are translates of one another: same length, same values entry by
+//        entry, window columns differing by one constant per row -- the rows of one node type inside a
+//        brick of a uniform mesh): ONE stored row, a dword at 256 j + 4 l, plus a window shift per row;
+//        one dictionary gather serves all rows.  96 % of the entries of the Stokes velocity block;
+//    of the last, partial chunk only the lanes below the batch's longest remainder are stored;
+//  * the 64-byte batch descriptor names the GLOBAL row of each row, so the sums go straight to y.
 //
-// An LDS-DMA variant of this kernel (global_load_lds_dwordx4 into per-wave stream buffers,
-// ds_read_u16 / ds_read_u8 decode) was measured slower (1.78 vs 1.36 ms at N = 74): the
-// in-flight bytes HBM latency demands (~45 KB per CU) fit the register file, not the LDS
-// that also holds the windows -- profiles/r02/lds_dma_experiment/.
+// At N = 74: 0.83 B/nnz, 0.53..0.58 ms per launch (round-1 kernel: 6.08 GB, 1.5 ms); bound by the vector
+// ALU (~72 % of the issue slots: window-offset adds, fma, the 4-row trees) and the LDS gather rate, not by
+// HBM.  History of the variants, incl. an LDS-DMA one that lost: DESIGN.md section 5, profiles/r02/.
 #pragma once
 
 namespace alfd {
