@@ -95,6 +95,48 @@ def test_batch_major_format_bitwise(built, blocks):
         ctx.close()
 
 
+def test_batch_major_format_edge_rows_bitwise(built):
+    """Batch-major format with structurally EMPTY rows (class 0 batches), single-entry rows, and a few
+    randomly perturbed rows that break the translate structure of their neighbours; and the refusal of a
+    matrix with one row beyond 384 entries (it keeps the round-1 formats, same result)."""
+    import scipy.sparse as sp
+    big = problems.generate(dim=3, degree=2, ncomp=3, n_cells=20, stokes=False, grad_div=True,
+                            gamma_grad_div=10.0, radius=0.1, immersed_refine=0)
+    a = big.mats["A"].to_scipy().tolil()
+    rng = np.random.default_rng(5)
+    for r in range(0, a.shape[0], 97):
+        a.rows[r], a.data[r] = [], []                      # empty rows
+    for r in range(50, a.shape[0], 1013):
+        a.rows[r], a.data[r] = a.rows[r][:1], a.data[r][:1]   # single-entry rows
+    a = a.tocsr()
+    for r in range(31, a.shape[0], 211):                   # perturbed values: no translate of anything
+        a.data[a.indptr[r]:a.indptr[r + 1]] *= 1.0 + 0.25 * rng.integers(1, 4)
+    m = problems.Csr.from_scipy(a)
+    x = _rng_vec(m.ncols, 7)
+    y0 = _rng_vec(m.nrows, 8)
+    ctx = solver.Context(0)
+    try:
+        ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(big.params, (8, 4, 2)))
+        ctx.set_matrix(_abi.A, m)
+        assert ctx.matrix_info(_abi.A)["batch_major"] == 2
+        for mode in (0, 1):
+            got, _ = ctx.spmv(_abi.A, x, y0, mode=mode, alpha=0.5)
+            ref, _ = oracle.spmv(m, x, y0 if mode else None, mode=mode, alpha=0.5)
+            assert np.array_equal(got, ref)
+        # one long row (> 384 entries): not representable, the other formats take over
+        long = a.tolil()
+        long.rows[1000] = list(range(0, 1200, 3))
+        long.data[1000] = [0.5] * 400
+        ml = problems.Csr.from_scipy(long.tocsr())
+        ctx.set_matrix(_abi.A, ml)
+        assert ctx.matrix_info(_abi.A)["batch_major"] == 0
+        got, _ = ctx.spmv(_abi.A, x, y0, mode=0)
+        ref, _ = oracle.spmv(ml, x, None, mode=0)
+        assert np.array_equal(got, ref)
+    finally:
+        ctx.close()
+
+
 def test_spmv_every_kernel_family_bitwise(built):
     """Matrices that exercise each lanes-per-row kernel, the sparse-row form, the
     streaming kernel and the LDS-windowed kernel (>= 2048 row blocks), incl.
