@@ -47,8 +47,8 @@ def main():
                     help="extra timed solves with the dictionary-free 10 B/nnz SpMV kernel (0 = skip)")
     ap.add_argument("--inner-prec", choices=["chebyshev", "multilevel"],
                     default=os.environ.get("ALFD_BENCH_PREC", "multilevel"))
-    ap.add_argument("--ml-smooth-degree", type=int, default=3)
-    ap.add_argument("--ml-smooth-ratio", type=float, default=64.0)
+    ap.add_argument("--ml-smooth-degree", type=int, default=4)
+    ap.add_argument("--ml-smooth-ratio", type=float, default=256.0)
     ap.add_argument("--ml-coarse-degree", type=int, default=10)
     ap.add_argument("--agg-a", type=int, default=2, help="nodes per aggregate edge (geometric aggregation)")
     ap.add_argument("--min-coarse", type=int, default=600, help="stop coarsening below this many unknowns")

@@ -154,12 +154,12 @@ def case(name):
         cfg.fgmres_flavour = _abi.FGMRES_DEALII_95
         cfg.restart = 5
     elif name == "stokes3d_bench_settings":
-        # exactly bench.py's solver settings (multigrid: Chebyshev(3) over [lmax/64, lmax], Chebyshev(10)
+        # exactly bench.py's solver settings (multigrid: Chebyshev(4) over [lmax/256, lmax], Chebyshev(10)
         # coarsest solve, geometric aggregates a = 2 / min_coarse 600, inner cap 100 = prm:23) at small N
         pb = problems.stokes3d_sphere(8, 1)
         cfg = _abi.default_config(_abi.AL_STOKES)
         cfg.inner_prec = _abi.PREC_MULTILEVEL
-        cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+        cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 4, 256.0, 10
         cfg.inner.max_steps = 100
         return pb, cfg
     else:

@@ -105,7 +105,7 @@ def test_partitioned_bench_like_solve_matches_single_rank(built):
     cfg = _abi.default_config(_abi.AL_STOKES)
     cfg.inner.max_steps = 100
     cfg.inner_prec = _abi.PREC_MULTILEVEL
-    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 4, 256.0, 10
     full = problems.stokes3d_sphere(n, ref)
     plan = partition.slab_partition_stokes3d(n, ref, world)
     levels = partition.partitioned_geometric_aggregates(full.params, plan, a=2, min_coarse=600)

@@ -577,7 +577,7 @@ def test_properties_cfg3_full_size(built, beta2):
     cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 100000, 1e-2, 1e-20)
     cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-10)
     cfg.inner_prec = _abi.PREC_MULTILEVEL
-    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 4, 256.0, 10
     aggs = problems.geometric_aggregates(pb, a=2, min_coarse=600)
     rhs = [pb.vecs["f"], pb.vecs["f2"], np.zeros(pb.block_sizes[2])]
     _full_size_properties(pb, cfg, rhs, aggs, (15, 60), False, False)
@@ -599,7 +599,7 @@ def test_properties_cfg5_full_size(built):
     cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 10000, 1e-2, 1e-20)    # prm:60-66
     cfg.outer = _abi.Control(_abi.CTRL_FIXED_ITERS, 12, 1e-10, 1e-6)
     cfg.inner_prec = _abi.PREC_MULTILEVEL
-    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 4, 256.0, 10
     aggs = problems.geometric_aggregates(pb, a=2, min_coarse=600)
     rhs = [pb.vecs["f"], pb.vecs["f2"], np.zeros(pb.block_sizes[2])]
     nr = pb.block_sizes[0]
@@ -616,7 +616,7 @@ def test_algebraic_aggregates_on_condensed_operator_parity(built):
     cfg = _abi.default_config(_abi.AL_STOKES)
     cfg.inner.max_steps = 100                       # the reference's cap (parameters_stokes_3d.prm:23)
     cfg.inner_prec = _abi.PREC_MULTILEVEL
-    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+    cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 4, 256.0, 10
     ctx = solver.Context(0)
     try:
         ctx.set_matrix(_abi.A, pb.mats["A"])

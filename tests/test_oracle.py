@@ -449,7 +449,7 @@ def test_algebraic_aggregation_on_a_condensed_operator():
         aggs = None
         if prec == "ml":
             cfg.inner_prec = _abi.PREC_MULTILEVEL
-            cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 3, 64.0, 10
+            cfg.ml_smooth_degree, cfg.ml_smooth_ratio, cfg.ml_coarse_degree = 4, 256.0, 10
             aggs = [(agg, nc)]
         osys = oracle.system_from_problem(pb, aggregates=aggs)
         rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
