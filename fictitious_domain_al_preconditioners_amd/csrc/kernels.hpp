@@ -88,11 +88,22 @@ __device__ __forceinline__ double group_reduce(double v) {
   return v;
 }
 
+// lane l <- lane l + N of its 16-lane row (row_shl:N; the top N lanes of a row keep 0)
+template <int N>
+__device__ __forceinline__ double dpp_shl(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int rl = __builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xf, 0xf, false);
+  const int rh = __builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xf, 0xf, false);
+  return __hiloint2double(rh, rl);
+}
+// Last four tree steps inside 16-lane rows, valid in lane 0 of every row (the lane that stores): after the
+// symmetric l^8 step lane l only takes its partner l + k -- the pairs of the canonical tree, and a + b is
+// b + a bit for bit -- which needs one DPP move per word instead of the two masked ones of an exchange.
 __device__ __forceinline__ double row16_tree(double v) {
   v = v + dpp_xor_mov(v, 8);
-  v = v + dpp_xor_mov(v, 4);
-  v = v + dpp_xor_mov(v, 2);
-  v = v + dpp_xor_mov(v, 1);
+  v = v + dpp_shl<4>(v);
+  v = v + dpp_shl<2>(v);
+  v = v + dpp_shl<1>(v);
   return v;
 }
 // Trees of 4 rows; the result of row q sits in the 16-lane row kRow4Pos(q).
@@ -104,6 +115,34 @@ __device__ __forceinline__ double reduce_rows4(double a0, double a1, double a2, 
   swap16(p, q);
   return row16_tree(p + q);  // 16-lane rows: row0, row2, row1, row3
 }
+// Trees of 8 rows, packed as far as the hardware swaps allow: after the l^32 and l^16 steps two registers
+// hold 4 rows x 16 lanes each; the l^8 step folds each to 8 lanes per row and the two are merged into ONE
+// register (lanes 0..7 of every 16-lane row: rows 0..3, lanes 8..15: rows 4..7); the last three steps only
+// feed the lane that stores (lane l takes its partner l + k: same pairs as the canonical tree, and a + b is
+// b + a bit for bit).  Result of row {0, 2, 1, 3}[lane >> 4] + 4 * ((lane >> 3) & 1) in lanes with lane % 8 == 0.
+__device__ __forceinline__ double reduce_rows8(double a0, double a1, double a2, double a3, double a4, double a5,
+                                               double a6, double a7, int lane) {
+  swap32(a0, a1);
+  double p01 = a0 + a1;
+  swap32(a2, a3);
+  double p23 = a2 + a3;
+  swap32(a4, a5);
+  double p45 = a4 + a5;
+  swap32(a6, a7);
+  double p67 = a6 + a7;
+  swap16(p01, p23);
+  double u = p01 + p23;  // 16-lane rows: row0, row2, row1, row3
+  swap16(p45, p67);
+  double w = p45 + p67;  // row4, row6, row5, row7
+  u = u + dpp_xor_mov(u, 8);
+  w = w + dpp_xor_mov(w, 8);
+  double x = (lane & 8) ? w : u;
+  x = x + dpp_shl<4>(x);
+  x = x + dpp_shl<2>(x);
+  x = x + dpp_shl<1>(x);
+  return x;
+}
+
 // Trees of 2 rows: row 0 in lanes 0..31, row 1 in lanes 32..63.
 __device__ __forceinline__ double reduce_rows2(double a0, double a1) {
   swap32(a0, a1);

@@ -229,8 +229,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         case 5: vs_shared<5, 8>(rem, sh, lane, fb, acc); break;
         default: vs_shared<6, 8>(rem, sh, lane, fb, acc); break;
       }
-      store4(reduce_rows4(acc[0], acc[1], acc[2], acc[3]), desc[0], desc[1], desc[2], desc[3]);
-      store4(reduce_rows4(acc[4], acc[5], acc[6], acc[7]), desc[4], desc[5], desc[6], desc[7]);
+      const double s8 = reduce_rows8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], lane);
+      // lane 16 q + 8 h (q = 0..3, h = 0..1) holds the tree of batch row {0, 2, 1, 3}[q] + 4 h
+      const bool h = (lane & 8) != 0, q1 = (lane & 16) != 0, q2 = (lane & 32) != 0;
+      const int32_t r0 = h ? (int32_t)(desc[4] >> 32) : (int32_t)(desc[0] >> 32);
+      const int32_t r1 = h ? (int32_t)(desc[5] >> 32) : (int32_t)(desc[1] >> 32);
+      const int32_t r2 = h ? (int32_t)(desc[6] >> 32) : (int32_t)(desc[2] >> 32);
+      const int32_t r3 = h ? (int32_t)(desc[7] >> 32) : (int32_t)(desc[3] >> 32);
+      const int32_t r = q2 ? (q1 ? r3 : r1) : (q1 ? r2 : r0);
+      if ((lane & 7) == 0 && r >= 0) {
+        if (EPI == 0)
+          y[r] = s8;
+        else if (EPI == 1)
+          y[r] = fma(alpha, s8, y[r]);
+        else if (EPI == 2)
+          y[r] = d[r] * s8;
+        else {
+          y[r] = s8;
+          y2[r] = d[r] * s8;
+        }
+      }
       continue;
     }
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
