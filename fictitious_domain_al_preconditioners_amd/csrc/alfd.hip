@@ -100,6 +100,7 @@ struct DevCsr {
     bool on = false, bricks = false;
     int64_t nb = 0, nseg = 0, stream_bytes = 0, nbatch = 0, dict_total = 0, shared_nnz = 0;
     int32_t stride = 0, maxW = 0;
+    int32_t L = 64, tab_u64 = 8;   // lanes per row of the format; descriptor words per batch
     uint8_t *stream = nullptr;
     int64_t *sb = nullptr;
     uint64_t *tab = nullptr;
@@ -111,7 +112,7 @@ struct DevCsr {
   double streamed_bytes(bool use_vi, bool use_vs = false) const {
     const double vec = (double)(n_list + 1) * 8.0 + (double)n_list * 8.0 + (double)(sparse ? n_list : ncols) * 8.0;
     if (vs.on && use_vs && use_vi)
-      return (double)vs.stream_bytes + 64.0 * (double)vs.nbatch + 28.0 * (double)vs.nb +
+      return (double)vs.stream_bytes + 8.0 * vs.tab_u64 * (double)vs.nbatch + 28.0 * (double)vs.nb +
              8.0 * (double)vs.nseg + 8.0 * (double)vs.dict_total + 8.0 * (double)nrows +
              8.0 * (double)(sparse ? n_list : ncols);
     if (!win) return (double)nnz * 12.0 + vec;
@@ -628,9 +629,35 @@ static bool launch_window_RU(alfd_ctx *ctx, const DevCsr &m, const double *x, do
 }
 
 
+template <int L>
+static void launch_vss(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
+                       const double *d, double *y2) {
+  const DevCsr::Vs &v = m.vs;
+  const size_t lds = (size_t)kVsWinOff + (size_t)v.maxW * sizeof(double);
+#define ALFD_VSS(EPI, TAG)                                                                                          \
+  hipLaunchKernelGGL((spmv_vss_kernel<L, EPI, TAG>), dim3((unsigned)v.nb), dim3(256), lds, ctx->stream, v.stream, \
+                     v.sb, v.tab, v.cnt, v.stride, v.seg_begin, v.blkW, v.seg_col, v.seg_off, v.doff, v.dn, v.dict, \
+                     x, m.halo, m.n_local_cols, y, alpha, d, y2)
+  if (m.tag == 0) {
+    if (epi == 0) ALFD_VSS(0, 0);
+    else if (epi == 1) ALFD_VSS(1, 0);
+    else if (epi == 2) ALFD_VSS(2, 0);
+    else ALFD_VSS(3, 0);
+  } else {
+    if (epi == 0) ALFD_VSS(0, 1);
+    else if (epi == 1) ALFD_VSS(1, 1);
+    else if (epi == 2) ALFD_VSS(2, 1);
+    else ALFD_VSS(3, 1);
+  }
+#undef ALFD_VSS
+}
+
 static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
                       const double *d, double *y2) {
   const DevCsr::Vs &v = m.vs;
+  if (v.L == 32) return launch_vss<32>(ctx, m, x, y, epi, alpha, d, y2), true;
+  if (v.L == 16) return launch_vss<16>(ctx, m, x, y, epi, alpha, d, y2), true;
+  if (v.L == 8) return launch_vss<8>(ctx, m, x, y, epi, alpha, d, y2), true;
   const int NW = ctx->vs_NW;
   const size_t lds = (size_t)kVsWinOff + (size_t)v.maxW * sizeof(double);
 #define ALFD_VS_ARGS                                                                                          \
@@ -678,7 +705,7 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
   }
   if (m.n_list == 0) return ALFD_OK;
   Timer tm(ctx, cls, m.algorithmic_bytes());
-  if (m.vs.on && ctx->vs_enable && !ctx->vi_off && launch_vs(ctx, m, x, y, epi, alpha, d, y2)) {
+  if (m.vs.on && ctx->vs_enable && !ctx->vi_off && launch_vs(ctx, m, x, y, epi, alpha, d, y2)) {   // vi_off: alfd_bench_spmv_format(…, 0)
     HIPC(hipGetLastError());
     return ALFD_OK;
   }
@@ -2054,7 +2081,7 @@ static int64_t vs_batch_units(const VsBatch &q, const std::vector<int32_t> &rows
 // kVsMaxRows rows, are halved until they fit; false if a single row does not fit.
 static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val, int RB, int64_t nb_in,
                              const int64_t *bptr, const int32_t *brows, std::vector<int64_t> &optr,
-                             std::vector<int32_t> &orows) {
+                             std::vector<int32_t> &orows, int max_rows = kVsMaxRows) {
   const bool nat = bptr == nullptr;
   const int64_t nb = nat ? (nrows + RB - 1) / RB : nb_in;
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -2081,7 +2108,7 @@ static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val
         while (!stack.empty() && !bad) {   // depth-first, left half first: pieces come out in row-list order
           const auto [a, e] = stack.back();
           stack.pop_back();
-          bool fits = e - a <= kVsMaxRows;
+          bool fits = e - a <= max_rows;
           if (fits) {
             ++gen;
             int distinct = 0;
@@ -2280,6 +2307,215 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
   pl.ok = true;
 }
 
+// ---- the same idea for SHORT rows (canonical L = 8, 16 or 32 lanes per row: Q1 stencils, the level operators of
+// scalar problems).  A 64-lane wave holds G = 64 / L rows side by side, a batch is ONE stored template row (a dword
+// per entry: 9-bit value code, 12-bit window column, ready-shifted) shared by up to 4 G translate rows -- on a
+// uniform mesh every interior row of a run is a translate of its neighbour, so the matrix stream all but vanishes
+// (27-point Laplace: 12 B/nnz CSR -> ~0.6 B/nnz incl. descriptors) and what is left is one LDS gather and one fma
+// per entry.  Rows without a translate partner are batches of one.  Descriptor per batch (uint64 words):
+//   [0] eb (20 bits, 16-byte units) | entry count (9) | class = ceil(count / L) (3) | rows in the batch (32)
+//   [1 + i] global row (32, low) | window shift in bytes (32, high, signed)      i = 0 .. 4 G - 1
+constexpr int kVssMaxClass = 4;   // rows of at most 4 L entries
+constexpr int kVssMaxRows = 512;  // rows per block
+struct VssBatch {
+  int cls, nreal;
+  std::vector<int> id;
+  std::vector<int32_t> shift;
+};
+
+static void plan_vss(int64_t nrows, int L, const int64_t *rp, const int32_t *col, const double *val, int RB, int maxW,
+                     int GAP, VsPlan &pl) {
+  const int RBb = 4 * (64 / L);   // rows per batch
+  std::vector<int64_t> r_ptr;
+  std::vector<int32_t> r_rows;
+  if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, 0, nullptr, nullptr, r_ptr, r_rows, kVssMaxRows)) return;
+  const int64_t *bptr = r_ptr.data();
+  const int32_t *brows = r_rows.data();
+  const int64_t nb = (int64_t)r_ptr.size() - 1;
+  if (nb == 0 || nb > 2147483000LL) return;
+  const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::vector<VssBatch>> batches(nb);
+  std::vector<int64_t> blk_units(nb, 0);
+  std::atomic<bool> bad(false);
+  std::atomic<int64_t> n_shared_nnz(0);
+  auto units_of = [&](const VssBatch &q) { return (int64_t)(q.cls * L + 3) / 4; };   // cls * L dwords, 16-byte units
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<int32_t> rows, first;
+        std::vector<int64_t> len;
+        std::vector<uint64_t> key;
+        std::vector<int> ids;
+        VsWindow w;
+        int64_t sh = 0;
+        for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
+          rows.assign(brows + bptr[b], brows + bptr[b + 1]);
+          if (!vs_window(rows, rp, col, GAP, maxW, w, nullptr, nullptr)) { bad = true; break; }
+          const int nr = (int)rows.size();
+          len.assign(nr, 0);
+          key.assign(nr, 0);
+          first.assign(nr, 0);
+          for (int i = 0; i < nr && !bad; ++i) {
+            const int64_t k0 = rp[rows[i]], n = rp[rows[i] + 1] - k0;
+            if (n > (int64_t)kVssMaxClass * L) { bad = true; break; }
+            len[i] = n;
+            uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+            const int32_t p0 = n ? w.pos[col[k0] - w.clo] : 0;
+            first[i] = p0;
+            for (int64_t k = 0; k < n; ++k) {
+              uint64_t bits;
+              std::memcpy(&bits, &val[k0 + k], 8);
+              h = (h ^ bits) * 0xff51afd7ed558ccdull;
+              h = (h ^ (uint64_t)(uint32_t)(w.pos[col[k0 + k] - w.clo] - p0)) * 0xc4ceb9fe1a85ec53ull;
+              h ^= h >> 29;
+            }
+            key[i] = h;
+          }
+          if (bad) break;
+          auto same = [&](int a, int c) {
+            if (len[a] != len[c]) return false;
+            const int64_t ka = rp[rows[a]], kc = rp[rows[c]];
+            for (int64_t k = 0; k < len[a]; ++k) {
+              if (std::memcmp(&val[ka + k], &val[kc + k], 8) != 0) return false;
+              if (w.pos[col[ka + k] - w.clo] - first[a] != w.pos[col[kc + k] - w.clo] - first[c]) return false;
+            }
+            return true;
+          };
+          std::vector<VssBatch> &out = batches[b];
+          for (int cls = 0; cls <= kVssMaxClass; ++cls) {
+            ids.clear();
+            for (int i = 0; i < nr; ++i)
+              if ((int)((len[i] + L - 1) / L) == cls) ids.push_back(i);
+            std::stable_sort(ids.begin(), ids.end(), [&](int a, int c) { return key[a] < key[c]; });
+            size_t g0 = 0;
+            while (g0 < ids.size()) {
+              size_t g1 = g0 + 1;
+              while (cls > 0 && g1 < ids.size() && key[ids[g1]] == key[ids[g0]] && same(ids[g0], ids[g1])) ++g1;
+              if (cls == 0) g1 = ids.size();   // empty rows: any number per batch
+              for (size_t q = g0; q < g1; q += RBb) {
+                VssBatch bt{cls, 0, {}, {}};
+                for (size_t i = q; i < std::min(q + (size_t)RBb, g1); ++i) {
+                  bt.id.push_back(ids[i]);
+                  bt.shift.push_back(first[ids[i]] - first[ids[q]]);
+                  ++bt.nreal;
+                }
+                if (bt.nreal > 1) sh += (int64_t)bt.nreal * len[bt.id[0]];
+                out.push_back(std::move(bt));
+              }
+              g0 = g1;
+            }
+          }
+          int64_t e = 0;
+          for (const VssBatch &q : out) e += units_of(q);
+          blk_units[b] = e;
+        }
+        n_shared_nnz += sh;
+      });
+    for (auto &x : th) x.join();
+  }
+  if (bad) return;
+  pl.nb = nb;
+  pl.shared_nnz = n_shared_nnz;
+  pl.sb.assign(nb, 0);
+  int64_t tot = 0;
+  int maxb = 1, maxr = 1;
+  for (int64_t b = 0; b < nb; ++b) {
+    pl.sb[b] = tot;
+    tot += 16 * blk_units[b];
+    if (blk_units[b] > 0xfffffLL) return;
+    maxb = std::max(maxb, (int)batches[b].size());
+    maxr = std::max(maxr, (int)(bptr[b + 1] - bptr[b]));
+    pl.nbatch += (int64_t)batches[b].size();
+  }
+  if (maxb > 0xffff) return;
+  const int W64 = 1 + RBb;   // descriptor words per batch
+  pl.stride = maxb;
+  pl.rbs = maxr;
+  pl.stream.assign((size_t)tot + 4096, 0);
+  pl.tab.assign((size_t)nb * maxb * W64, 0);
+  pl.cnt.assign(nb, 0);
+  pl.blkW.assign(nb, 0);
+  pl.dn.assign(nb, 0);
+  std::vector<int32_t> blk_nseg(nb, 0);
+  std::vector<std::vector<double>> t_dict(T);
+  std::vector<std::vector<int32_t>> t_seg_col(T), t_seg_off(T), t_doff(T);
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<int32_t> rows;
+        VsWindow w;
+        constexpr int kTab = 1024;
+        std::vector<uint64_t> keys(kTab);
+        std::vector<int16_t> ids(kTab);
+        for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
+          rows.assign(brows + bptr[b], brows + bptr[b + 1]);
+          const std::vector<VssBatch> &bts = batches[b];
+          pl.cnt[b] = (int32_t)bts.size();
+          t_doff[t].push_back((int32_t)t_dict[t].size());
+          vs_window(rows, rp, col, GAP, maxW, w, &t_seg_col[t], &t_seg_off[t]);
+          pl.blkW[b] = w.W;
+          blk_nseg[b] = w.nseg;
+          std::fill(ids.begin(), ids.end(), (int16_t)-1);
+          const size_t d0 = t_dict[t].size();
+          uint8_t *sp = pl.stream.data() + pl.sb[b];
+          uint32_t eoff = 0;
+          for (size_t q = 0; q < bts.size() && !bad; ++q) {
+            const VssBatch &bt = bts[q];
+            uint64_t *dst = &pl.tab[((size_t)b * maxb + q) * W64];
+            const int32_t r0 = rows[bt.id[0]];
+            const int64_t k0 = rp[r0], n = rp[r0 + 1] - k0;
+            for (int64_t k = 0; k < n; ++k) {
+              uint64_t bits;
+              std::memcpy(&bits, &val[k0 + k], 8);
+              uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
+              for (;;) {
+                if (ids[h] < 0) {
+                  if (t_dict[t].size() - d0 == (size_t)kVsMaxDict) { bad = true; break; }
+                  keys[h] = bits;
+                  ids[h] = (int16_t)(t_dict[t].size() - d0);
+                  t_dict[t].push_back(val[k0 + k]);
+                  break;
+                }
+                if (keys[h] == bits) break;
+                h = (h + 1) & (kTab - 1);
+              }
+              if (bad) break;
+              const uint32_t f = ((uint32_t)ids[h] << 15) | ((uint32_t)w.pos[col[k0 + k] - w.clo] << 3);
+              std::memcpy(sp + 16 * (size_t)eoff + 4 * (size_t)k, &f, 4);
+            }
+            dst[0] = (uint64_t)eoff | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) | ((uint64_t)bt.nreal << 32);
+            for (int i = 0; i < RBb; ++i) {
+              const uint32_t row = i < bt.nreal ? (uint32_t)rows[bt.id[i]] : 0xffffffffu;
+              const int32_t shb = i < bt.nreal ? bt.shift[i] * 8 : 0;
+              dst[1 + i] = (uint64_t)row | ((uint64_t)(uint32_t)shb << 32);
+            }
+            eoff += (uint32_t)units_of(bt);
+          }
+          pl.dn[b] = (int32_t)(t_dict[t].size() - d0);
+        }
+      });
+    for (auto &x : th) x.join();
+  }
+  if (bad) return;
+  pl.seg_begin.assign(nb + 1, 0);
+  for (int64_t b = 0; b < nb; ++b) pl.seg_begin[b + 1] = pl.seg_begin[b] + blk_nseg[b];
+  pl.doff.reserve(nb);
+  for (int t = 0; t < T; ++t) {
+    const int32_t base = (int32_t)pl.dict.size();
+    for (int32_t o : t_doff[t]) pl.doff.push_back(base + o);
+    pl.dict.insert(pl.dict.end(), t_dict[t].begin(), t_dict[t].end());
+    pl.seg_col.insert(pl.seg_col.end(), t_seg_col[t].begin(), t_seg_col[t].end());
+    pl.seg_off.insert(pl.seg_off.end(), t_seg_off[t].begin(), t_seg_off[t].end());
+  }
+  if (pl.dict.size() > 2000000000ull) return;
+  int32_t mw = 1;
+  for (int64_t b = 0; b < nb; ++b) mw = std::max(mw, pl.blkW[b]);
+  pl.maxW = mw;
+  pl.ok = true;
+}
+
 static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const int32_t *col, const double *val) {
   VsPlan pl;
   const bool hint = slot >= 0 && slot < ALFD_NSLOTS && !ctx->rb_ptr[slot].empty();
@@ -2330,6 +2566,46 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
                  "entries in template-shared batches\n",
                  (long long)pl.nb, hint ? "caller's row blocks" : "runs of the numbering", (long long)pl.nbatch, pl.maxW,
                  (double)v.stream_bytes / (double)std::max<int64_t>(m.nnz, 1),
+                 100.0 * (double)pl.shared_nnz / (double)std::max<int64_t>(m.nnz, 1));
+  return ALFD_OK;
+}
+
+static int build_vss(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col, const double *val) {
+  VsPlan pl;
+  const int RB = std::min(kVssMaxRows, std::max(64, ctx->win_RB * std::max(1, ctx->win_short_scale) * 64 / m.L));
+  plan_vss(m.nrows, m.L, rp, col, val, RB, ctx->win_maxW, ctx->win_gap, pl);
+  // worthwhile only if rows do share templates (otherwise a dword per entry + descriptors buys nothing over the
+  // 10 B/nnz window format... it still halves the stream, but the L-lane window kernel is the tested default)
+  if (!pl.ok || pl.shared_nnz * 2 < m.nnz) return ALFD_OK;
+  DevCsr::Vs &v = m.vs;
+  RC(upload_vec(ctx, m, &v.stream, pl.stream));
+  RC(upload_vec(ctx, m, &v.sb, pl.sb));
+  RC(upload_vec(ctx, m, &v.tab, pl.tab));
+  RC(upload_vec(ctx, m, &v.cnt, pl.cnt));
+  RC(upload_vec(ctx, m, &v.seg_begin, pl.seg_begin));
+  RC(upload_vec(ctx, m, &v.blkW, pl.blkW));
+  RC(upload_vec(ctx, m, &v.seg_col, pl.seg_col));
+  RC(upload_vec(ctx, m, &v.seg_off, pl.seg_off));
+  RC(upload_vec(ctx, m, &v.doff, pl.doff));
+  RC(upload_vec(ctx, m, &v.dn, pl.dn));
+  RC(upload_vec(ctx, m, &v.dict, pl.dict));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  v.nb = pl.nb;
+  v.nseg = (int64_t)pl.seg_col.size();
+  v.stream_bytes = (int64_t)pl.stream.size() - 4096;
+  v.nbatch = pl.nbatch;
+  v.shared_nnz = pl.shared_nnz;
+  v.dict_total = (int64_t)pl.dict.size();
+  v.stride = pl.stride;
+  v.maxW = pl.maxW;
+  v.L = m.L;
+  v.tab_u64 = 1 + 4 * (64 / m.L);
+  v.bricks = false;
+  v.on = true;
+  if (ctx->cfg.log_level > 0)
+    std::fprintf(stderr, "[alfd] batch-major format (L = %d): %lld blocks, %lld batches, window <= %d slots, %.2f B/nnz, "
+                 "%.1f %% of the entries in shared batches\n", m.L, (long long)pl.nb, (long long)pl.nbatch, pl.maxW,
+                 (double)(v.stream_bytes + 8.0 * v.tab_u64 * v.nbatch) / (double)std::max<int64_t>(m.nnz, 1),
                  100.0 * (double)pl.shared_nnz / (double)std::max<int64_t>(m.nnz, 1));
   return ALFD_OK;
 }
@@ -2459,6 +2735,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
   if (ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0)
     RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot));
   if (ctx->vs_enable && m.vi && m.L == 64) RC(build_vs(ctx, m, slot, rp, col_up, val));
+  if (ctx->vs_enable && m.win && (m.L == 32 || m.L == 16 || m.L == 8)) RC(build_vss(ctx, m, rp, col_up, val));
   m.present = true;
   return ALFD_OK;
 }
@@ -4351,6 +4628,67 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
             const uint8_t *cell = fb + 768 * (size_t)(k / 64) + 12 * (size_t)(k % 64) + 3 * i;
             f = cell[0] | ((uint32_t)cell[1] << 8) | ((uint32_t)cell[2] << 16);
           }
+          if ((f & 7u) || (f >> 24)) ++bad;
+          const int32_t lcv = (int32_t)((f >> 3) & 0xfffu) + shift / 8;
+          const uint32_t vcv = f >> 15;
+          const double v = (int32_t)vcv < pl.dn[b] ? pl.dict[pl.doff[b] + vcv] : std::nan("");
+          const int32_t c = (lcv >= 0 && lcv < pl.blkW[b]) ? slot_col[lcv] : -1;
+          if (c != col[rp[r] + k] || std::memcmp(&v, &val[rp[r] + k], 8) != 0) ++bad;
+        }
+      }
+    }
+  }
+  out->decode_mismatches = bad;
+  out->rows_covered = covered;
+  return ALFD_OK;
+}
+
+int alfd_host_stream_plan_short(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int32_t lanes,
+                                alfd_stream_plan_info *out) {
+  if (!rp || !out || nrows < 0 || (lanes != 8 && lanes != 16 && lanes != 32)) return ALFD_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  VsPlan pl;
+  const int L = lanes, RBb = 4 * (64 / L), W64 = 1 + RBb;
+  plan_vss(nrows, L, rp, col, val, std::min(kVssMaxRows, 96 * 2 * 64 / L), 4096, 8, pl);
+  out->ok = pl.ok ? 1 : 0;
+  if (!pl.ok) return ALFD_OK;
+  out->max_window = pl.maxW;
+  out->max_rows = pl.rbs;
+  out->max_batches = pl.stride;
+  out->blocks = pl.nb;
+  out->batches = pl.nbatch;
+  out->segments = (int64_t)pl.seg_col.size();
+  out->dictionary_entries = (int64_t)pl.dict.size();
+  out->stream_bytes = (int64_t)pl.stream.size() - 4096 + 8 * (int64_t)W64 * pl.nbatch;
+  out->shared_nnz = pl.shared_nnz;
+  std::vector<uint8_t> seen(nrows, 0);
+  int64_t bad = 0, covered = 0;
+  std::vector<int32_t> slot_col;
+  for (int64_t b = 0; b < pl.nb; ++b) {
+    slot_col.assign(pl.blkW[b], -1);
+    for (int32_t s = pl.seg_begin[b]; s < pl.seg_begin[b + 1]; ++s) {
+      const int32_t end = s + 1 < pl.seg_begin[b + 1] ? pl.seg_off[s + 1] : pl.blkW[b];
+      for (int32_t o = pl.seg_off[s]; o < end; ++o) slot_col[o] = pl.seg_col[s] + (o - pl.seg_off[s]);
+    }
+    const uint8_t *sp = pl.stream.data() + pl.sb[b];
+    for (int q = 0; q < pl.cnt[b]; ++q) {
+      const uint64_t *dsc = &pl.tab[((size_t)b * pl.stride + q) * W64];
+      const uint32_t eb = (uint32_t)dsc[0] & 0xfffffu, n = ((uint32_t)dsc[0] >> 20) & 0x1ffu;
+      const int cls = (int)(((uint32_t)dsc[0] >> 29) & 7u), nreal = (int)(dsc[0] >> 32);
+      if ((int)((n + L - 1) / L) != cls || nreal < 1 || nreal > RBb) ++bad;
+      for (int i = 0; i < RBb; ++i) {
+        const int64_t r = (int32_t)(uint32_t)dsc[1 + i];
+        const int32_t shift = (int32_t)(dsc[1 + i] >> 32);
+        if (r < 0) {
+          if (i < nreal) ++bad;
+          continue;
+        }
+        if (i >= nreal || r >= nrows || seen[r] || (int64_t)n != rp[r + 1] - rp[r] || shift % 8) { ++bad; continue; }
+        seen[r] = 1;
+        ++covered;
+        for (uint32_t k = 0; k < n; ++k) {
+          uint32_t f;
+          std::memcpy(&f, sp + 16 * (size_t)eb + 4 * (size_t)k, 4);
           if ((f & 7u) || (f >> 24)) ++bad;
           const int32_t lcv = (int32_t)((f >> 3) & 0xfffu) + shift / 8;
           const uint32_t vcv = f >> 15;

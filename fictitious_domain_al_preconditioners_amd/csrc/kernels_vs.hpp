@@ -285,4 +285,105 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   }
 }
 
+// --------------------------------------------------------------------------
+// The same storage idea for SHORT rows (canonical L = 8, 16 or 32 lanes per row).  A wave holds G = 64 / L rows
+// side by side; a batch is one stored template row (a dword per entry) shared by up to 4 G rows that are
+// translates of one another, each with its own window shift (plan_vss in alfd.hip).  Lane (g, l) -- group g,
+// lane l of the group -- accumulates entry l + L j of rows g, G + g, 2 G + g, 3 G + g in four registers and
+// reduces each with the canonical L-lane tree: the result is the canonical one bit for bit.
+template <int L, int EPI, int TAG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_vss_kernel(
+    const uint8_t *__restrict__ stream, const int64_t *__restrict__ sb, const uint64_t *__restrict__ tab,
+    const int32_t *__restrict__ cnt, int32_t stride, const int32_t *__restrict__ blk_seg_begin,
+    const int32_t *__restrict__ blk_W, const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
+    const int32_t *__restrict__ blk_dict_off, const int32_t *__restrict__ blk_dict_n,
+    const double *__restrict__ dict, const double *__restrict__ x, const double *__restrict__ x_halo,
+    int32_t n_local, double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2) {
+  extern __shared__ double xs[];
+  constexpr int G = 64 / L, W64 = 1 + 4 * G, NW = 4;
+  char *sm = (char *)xs;
+  double *ds = (double *)(sm + kVsDictOff);
+  double *xw = (double *)(sm + kVsWinOff);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l = lane & (L - 1), g = lane / L;
+  const int64_t b = blockIdx.x;
+  const int32_t nbatch = cnt[b];
+  const uint8_t *sbase = stream + sb[b];
+  {  // block frame: dictionary and x window (as in spmv_vs_kernel)
+    const int32_t nd = blk_dict_n[b];
+    for (int t = threadIdx.x; t < nd; t += 64 * NW) ds[t] = dict[blk_dict_off[b] + t];
+    const int32_t W = blk_W[b];
+    const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
+    constexpr int U = 4;
+    for (int32_t s = s0 + wave * U; s < s1; s += NW * U) {
+      int32_t c0[U], o0[U], sl[U];
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t q = s + u < s1 ? s + u : s1 - 1;
+        c0[u] = seg_col[q];
+        o0[u] = seg_off[q];
+        sl[u] = ((q + 1 < s1) ? seg_off[q + 1] : W) - o0[u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t c = c0[u] + (lane < sl[u] ? lane : 0);
+        v[u] = (c < n_local) ? x[c] : x_halo[c - n_local];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (lane < sl[u]) xw[o0[u] + lane] = v[u];
+    }
+  }
+  __syncthreads();
+  for (int32_t bi = wave; bi < nbatch; bi += NW) {
+    const uint64_t *dsc = tab + ((int64_t)b * stride + bi) * W64;
+    const uint64_t h = dsc[0];
+    const uint32_t eb = vs_off(h);
+    const int32_t len = vs_len(h);
+    const int cls = vs_cls(h);
+    int32_t row[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint64_t e = dsc[1 + q * G + g];
+      row[q] = (int32_t)(uint32_t)e;
+      sh[q] = (int32_t)(e >> 32);
+    }
+    const uint8_t *fb = sbase + 16u * (size_t)eb;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < cls; ++j) {
+      const int32_t k = L * j + l;
+      const bool ok = k < len;
+      const uint32_t f = ok ? *(const uint32_t *)(fb + 4 * k) : 0u;
+      const uint32_t lc = f & 0x7ff8u;
+      const double v = vs_lds_f64(kVsDictOff + ((f >> 12) & 0xff8u));
+      double xv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xv[q] = vs_lds_f64(kVsWinOff + (uint32_t)((int32_t)lc + sh[q]));
+      if (ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fma(v, xv[q], acc[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double s = group_reduce<L>(acc[q]);
+      const int32_t r = row[q];
+      if (l == 0 && r >= 0) {
+        if (EPI == 0)
+          y[r] = s;
+        else if (EPI == 1)
+          y[r] = fma(alpha, s, y[r]);
+        else if (EPI == 2)
+          y[r] = d[r] * s;
+        else {
+          y[r] = s;
+          y2[r] = d[r] * s;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace alfd

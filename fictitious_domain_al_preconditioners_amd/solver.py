@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "alfd_host_window_plan", "alfd_set_tunable", "alfd_build_aggregates", "alfd_get_aggregates",
     "alfd_host_aggregate_level", "alfd_comm_init_host",
     "alfd_get_device_memory", "alfd_set_row_blocks", "alfd_host_stream_plan",
-    "alfd_host_row_blocks_from_points",
+    "alfd_host_row_blocks_from_points", "alfd_host_stream_plan_short",
 ]
 
 
@@ -106,6 +106,7 @@ def load_library():
         "alfd_set_row_blocks": (C.c_int, [vp, C.c_int, i64, vp, vp]),
         "alfd_host_stream_plan": (C.c_int, [i64, vp, vp, vp, C.c_int32, i64, vp, vp, vp]),
         "alfd_host_row_blocks_from_points": (C.c_int, [i64, C.c_int32, vp, C.c_int32, vp, vp, vp]),
+        "alfd_host_stream_plan_short": (C.c_int, [i64, vp, vp, vp, C.c_int32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -411,6 +412,19 @@ def host_window_plan(m, lanes=64, value_index=True):
                                    int(value_index), C.byref(info))
     if rc != _abi.OK:
         raise AlfdError(rc, "alfd_host_window_plan failed")
+    return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+def host_stream_plan_short(m, lanes):
+    """Host-only plan + decode of the short-row batch-major form (alfd_host_stream_plan_short; lanes = 8, 16, 32)."""
+    lib = load_library()
+    rp = np.ascontiguousarray(m.row_ptr, np.int64)
+    col = np.ascontiguousarray(m.col, np.int32)
+    val = np.ascontiguousarray(m.val, np.float64)
+    info = _abi.StreamPlanInfo()
+    rc = lib.alfd_host_stream_plan_short(m.nrows, rp.ctypes.data, col.ctypes.data, val.ctypes.data, lanes, C.byref(info))
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_stream_plan_short failed")
     return {k: getattr(info, k) for k, _ in info._fields_}
 
 

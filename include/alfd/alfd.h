@@ -398,6 +398,11 @@ typedef struct alfd_stream_plan_info {
 int alfd_host_stream_plan(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
                           int32_t row_block, int64_t n_blocks, const int64_t *block_ptr, const int32_t *rows,
                           alfd_stream_plan_info *out);
+/* The same for a short-row matrix (lanes = 8, 16 or 32, see alfd_matrix_lanes): the batch-major form of
+ * spmv_vss_kernel -- one stored template row per batch of translate rows -- planned on runs of the numbering and
+ * decoded back.  stream_bytes includes the batch descriptors. */
+int alfd_host_stream_plan_short(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                                int32_t lanes, alfd_stream_plan_info *out);
 /* alfd_bench_spmv with the value-indexed kernel switched on (1) or off (0: the same
  * matrix through the 10 B/nnz window kernel); streamed_bytes as in alfd_matrix_info. */
 int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value_index,

@@ -137,6 +137,39 @@ def test_batch_major_format_edge_rows_bitwise(built):
         ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["lap3d_L32", "q2_2d_L16", "lap2d_L8", "lap3d_perturbed"])
+def test_batch_major_short_rows_bitwise(built, kind):
+    """spmv_vss_kernel: the batch-major form for short rows (canonical L = 32 / 16 / 8 lanes per row): one stored
+    template row per batch of translate rows.  Stencil operators of uniform grids, and one with every 7th row
+    perturbed (rows without a translate partner are batches of one); both epilogues; against the oracle."""
+    gen = {"lap3d_L32": dict(dim=3, degree=1, ncomp=1, n_cells=74), "q2_2d_L16": dict(dim=2, degree=2, ncomp=1, n_cells=365),
+           "lap2d_L8": dict(dim=2, degree=1, ncomp=1, n_cells=724), "lap3d_perturbed": dict(dim=3, degree=1, ncomp=1, n_cells=74)}[kind]
+    m = problems.generate(radius=0.1, **gen).mats["A"]
+    if kind == "lap3d_perturbed":
+        v = np.array(m.val, copy=True)
+        for r in range(3, m.nrows, 7):
+            v[m.row_ptr[r]:m.row_ptr[r + 1]] *= 1.0 + 0.125 * (r % 5)
+        m = problems.Csr(m.nrows, m.ncols, np.array(m.row_ptr), np.array(m.col), v)
+    x = _rng_vec(m.ncols, 5)
+    y0 = _rng_vec(m.nrows, 6)
+    ctx = solver.Context(0)
+    try:
+        ctx.set_matrix(_abi.A, m)
+        info = ctx.matrix_info(_abi.A)
+        assert info["lanes"] == {"lap3d_L32": 32, "q2_2d_L16": 16, "lap2d_L8": 8, "lap3d_perturbed": 32}[kind]
+        assert info["windowed"] and info["batch_major"] == 1, info
+        assert info["streamed_bytes"] < 4.0 * m.nnz + 16.0 * m.nrows
+        for mode in (0, 1):
+            got, lanes = ctx.spmv(_abi.A, x, y0, mode=mode, alpha=-0.75)
+            ref, olanes = oracle.spmv(m, x, y0 if mode else None, mode=mode, alpha=-0.75)
+            assert lanes == olanes and np.array_equal(got, ref), (kind, mode)
+        ctx.set_tunable("batch_major", 0)           # the L-lane window kernel on the same slot: same bits
+        got, _ = ctx.spmv(_abi.A, x, y0, mode=0)
+        assert np.array_equal(got, oracle.spmv(m, x, None, mode=0)[0])
+    finally:
+        ctx.close()
+
+
 def test_spmv_every_kernel_family_bitwise(built):
     """Matrices that exercise each lanes-per-row kernel, the sparse-row form, the
     streaming kernel and the LDS-windowed kernel (>= 2048 row blocks), incl.
