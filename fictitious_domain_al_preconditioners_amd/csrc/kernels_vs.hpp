@@ -337,40 +337,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
   }
   __syncthreads();
+  // software pipeline over the wave's batches: header two batches ahead (scalar), rows / shifts / template
+  // words one batch ahead (a fixed four predicated loads each, so the compiler's wait counts stay exact)
+  const uint64_t *dsc = tab + ((int64_t)b * stride + wave) * W64;
+  auto load_batch = [&](const uint64_t *dp, uint64_t hh, uint64_t (&e)[4], uint32_t (&f)[4]) {
+    const uint8_t *fbp = sbase + 16u * (size_t)vs_off(hh);
+    const int32_t ln = vs_len(hh);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = dp[1 + q * G + g];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int32_t k = L * j + l;
+      f[j] = k < ln ? *(const uint32_t *)(fbp + 4 * k) : 0u;   // k < len implies j < class
+    }
+  };
+  uint64_t h1 = 0, h2 = 0;
+  uint64_t e_cur[4] = {0, 0, 0, 0}, e_nxt[4] = {0, 0, 0, 0};
+  uint32_t f_cur[4] = {0, 0, 0, 0}, f_nxt[4] = {0, 0, 0, 0};
+  if (wave < nbatch) {
+    h1 = dsc[0];
+    load_batch(dsc, h1, e_cur, f_cur);
+  }
+  if (wave + NW < nbatch) h2 = dsc[(size_t)NW * W64];
   for (int32_t bi = wave; bi < nbatch; bi += NW) {
-    const uint64_t *dsc = tab + ((int64_t)b * stride + bi) * W64;
-    const uint64_t h = dsc[0];
-    const uint32_t eb = vs_off(h);
-    const int32_t len = vs_len(h);
-    const int cls = vs_cls(h);
+    uint64_t h3 = 0;
+    if (bi + 2 * NW < nbatch) h3 = dsc[(size_t)2 * NW * W64];
+    if (bi + NW < nbatch) load_batch(dsc + (size_t)NW * W64, h2, e_nxt, f_nxt);
+    const int32_t len = vs_len(h1);
+    const int cls = vs_cls(h1);
     int32_t row[4], sh[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint64_t e = dsc[1 + q * G + g];
-      row[q] = (int32_t)(uint32_t)e;
-      sh[q] = (int32_t)(e >> 32);
+      row[q] = (int32_t)(uint32_t)e_cur[q];
+      sh[q] = (int32_t)(e_cur[q] >> 32);
     }
-    const uint8_t *fb = sbase + 16u * (size_t)eb;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int j = 0; j < cls; ++j) {
-      const int32_t k = L * j + l;
-      const bool ok = k < len;
-      const uint32_t f = ok ? *(const uint32_t *)(fb + 4 * k) : 0u;
-      const uint32_t lc = f & 0x7ff8u;
-      const double v = vs_lds_f64(kVsDictOff + ((f >> 12) & 0xff8u));
-      double xv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xv[q] = vs_lds_f64(kVsWinOff + (uint32_t)((int32_t)lc + sh[q]));
-      if (ok) {
+    for (int j = 0; j < 4; ++j) {
+      if (j < cls) {   // wave-uniform
+        const uint32_t f = f_cur[j];
+        const uint32_t lc = f & 0x7ff8u;
+        const double v = vs_lds_f64(kVsDictOff + ((f >> 12) & 0xff8u));
+        double xv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = fma(v, xv[q], acc[q]);
+        for (int q = 0; q < 4; ++q) xv[q] = vs_lds_f64(kVsWinOff + (uint32_t)((int32_t)lc + sh[q]));
+        if (L * j + l < len) {
+          asm volatile("");
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = fma(v, xv[q], acc[q]);
+        }
       }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double s = group_reduce<L>(acc[q]);
-      const int32_t r = row[q];
-      if (l == 0 && r >= 0) {
+    auto store = [&](double s, int32_t r, bool writer) {
+      if (writer && r >= 0) {
         if (EPI == 0)
           y[r] = s;
         else if (EPI == 1)
@@ -382,7 +401,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
           y2[r] = d[r] * s;
         }
       }
+    };
+    // canonical L-lane trees of the 4 x G rows, packed where the hardware exchanges allow and one-directional
+    // towards the lane that stores (same pairs as group_reduce<L>; a + b is b + a bit for bit)
+    const bool w8 = (lane & 7) == 0, h8 = (lane & 8) != 0;
+    if (L == 32) {
+      // acc[q]: lanes 0..31 row (q, g = 0), lanes 32..63 row (q, g = 1)
+      swap16(acc[0], acc[1]);
+      double u = acc[0] + acc[1];   // 16-lane rows: (q0, g0), (q1, g0), (q0, g1), (q1, g1)
+      swap16(acc[2], acc[3]);
+      double w = acc[2] + acc[3];   // (q2, g0), (q3, g0), (q2, g1), (q3, g1)
+      u = u + dpp_xor_mov(u, 8);
+      w = w + dpp_xor_mov(w, 8);
+      double t = h8 ? w : u;
+      t = t + dpp_shl<4>(t);
+      t = t + dpp_shl<2>(t);
+      t = t + dpp_shl<1>(t);
+      const bool odd = (lane & 16) != 0;   // lane 16 rr + 8 h holds row q = (rr & 1) + 2 h of this lane's group
+      const int32_t r = h8 ? (odd ? row[3] : row[2]) : (odd ? row[1] : row[0]);
+      store(t, r, w8);
+    } else if (L == 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = acc[q] + dpp_xor_mov(acc[q], 8);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {   // lanes 0..7 of a 16-lane row: row 2 p, lanes 8..15: row 2 p + 1 (of group g)
+        double t = h8 ? acc[2 * p + 1] : acc[2 * p];
+        t = t + dpp_shl<4>(t);
+        t = t + dpp_shl<2>(t);
+        t = t + dpp_shl<1>(t);
+        store(t, h8 ? row[2 * p + 1] : row[2 * p], w8);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double t = acc[q];
+        t = t + dpp_shl<4>(t);
+        t = t + dpp_shl<2>(t);
+        t = t + dpp_shl<1>(t);
+        store(t, row[q], w8);
+      }
     }
+    dsc += (size_t)NW * W64;
+    h1 = h2;
+    h2 = h3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e_cur[q] = e_nxt[q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f_cur[j] = f_nxt[j];
   }
 }
 
