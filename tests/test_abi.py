@@ -116,6 +116,27 @@ def test_host_stream_plan_decodes_back():
     assert not solver.host_stream_plan(rnd)["ok"]
 
 
+def test_host_stream_plan_short_rows_decodes_back():
+    """The short-row batch-major form (spmv_vss_kernel: one stored template row per batch of translate rows)
+    planned on the host decodes back to the CSR, for L = 32 / 16 / 8 lanes per row; nearly every entry of a
+    stencil operator sits in a shared batch; rows longer than 4 L are refused."""
+    import numpy as np
+    from fictitious_domain_al_preconditioners_amd import problems
+    for gen, lanes in ((dict(dim=3, degree=1, ncomp=1, n_cells=24), 32), (dict(dim=2, degree=2, ncomp=1, n_cells=60), 16),
+                       (dict(dim=2, degree=1, ncomp=1, n_cells=120), 8)):
+        a = problems.generate(radius=0.1, **gen).mats["A"]
+        info = solver.host_stream_plan_short(a, lanes)
+        assert info["ok"] and info["decode_mismatches"] == 0 and info["rows_covered"] == a.nrows, (lanes, info)
+        assert info["shared_nnz"] > 0.9 * a.nnz and info["stream_bytes"] < 2.5 * a.nnz
+    rng = np.random.default_rng(2)
+    v = np.array(a.val) * (1.0 + 0.25 * rng.integers(0, 3, a.nnz))          # rows no longer translates
+    info = solver.host_stream_plan_short(problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), v), 8)
+    assert info["ok"] and info["decode_mismatches"] == 0 and info["shared_nnz"] < 0.5 * a.nnz
+    import scipy.sparse as sp
+    wide = problems.Csr.from_scipy(sp.random(400, 400, density=0.2, random_state=1, format="csr"))   # ~80 per row
+    assert not solver.host_stream_plan_short(wide, 8)["ok"]
+
+
 def test_row_blocks_from_support_points():
     """alfd_host_row_blocks_from_points: a partition of the rows into spatially compact blocks of at most
     max_rows rows, usable as alfd_set_row_blocks input without grid metadata (window well below that of
