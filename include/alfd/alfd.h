@@ -429,6 +429,12 @@ int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_b
  *   "value_index"  1 (default): matrices whose row blocks were dictionary-coded at upload use the
  *                  3 B/nnz kernel; 0: every windowed matrix goes through the general 10 B/nnz kernel
  *                  (8-byte values + 16-bit window columns), as a matrix with unrelated values would.
+ *   "batch_major"  1 (default): long-row matrices with repeating values, and short-row (8 / 16 / 32 lanes per
+ *                  row) matrices whose rows are mostly translates of one another, use the batch-major forms of
+ *                  csrc/kernels_vs.hpp (decided at alfd_set_matrix; also switches the kernel at launch); 0: the
+ *                  round-1 window formats.  "batch_major_rows" (4..250, default 96): rows per block of the long-row
+ *                  form when no alfd_set_row_blocks hint is given; "batch_major_waves" (2, 4, 8): waves per workgroup;
+ *                  "batch_major_xcd" (0/1): XCD-contiguous block order (measured slower).
  * Returns ALFD_E_INVALID for an unknown name. */
 int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value);
 /* Kernel-class timing of the last solve, accumulated with HIP events when
