@@ -226,6 +226,30 @@ def main():
                    "bytes_per_launch": g_bytes, "achieved": g_bytes / (g_ms * 1e-3) / 1e9,
                    "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+    # ---- and with translate sharing off: every row stored (3.1 B/nnz), what a matrix whose values repeat but whose
+    # rows are no translates of one another (unstructured mesh) gets from the batch-major kernel
+    unshared = None
+    if world == 1 and info["batch_major"] and args.general_steps > 0:
+        ctx.set_tunable("batch_major_share", 0)
+        solver.upload_problem(ctx, pb, cfg, aggregates, row_blocks)
+        ctx.upload_rhs(rhs)
+        ctx.solve_resident()
+        ctx.enable_timing(True)
+        barrier()
+        u0 = time.perf_counter()
+        ures = ctx.solve_resident()
+        barrier()
+        udt = time.perf_counter() - u0
+        ut = ctx.timing()["spmv_A"]
+        ctx.enable_timing(False)
+        uinfo = ctx.matrix_info(_abi.A)
+        u_ms = ut["ms"] / max(ut["launches"], 1)
+        unshared = {"what": "batch-major kernel with every row stored (no translate sharing)", "ms_per_step": udt * 1e3,
+                    "value": ures.outer_iterations / udt, "unit": "iterations/s", "avg_launch_ms": u_ms,
+                    "bytes_per_launch": uinfo["streamed_bytes"], "bytes_per_nnz": uinfo["streamed_bytes"] / max(uinfo["nnz"], 1),
+                    "achieved": uinfo["streamed_bytes"] / (u_ms * 1e-3) / 1e9 if u_ms > 0 else 0.0,
+                    "frac": uinfo["streamed_bytes"] / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if u_ms > 0 else 0.0}
+        ctx.set_tunable("batch_major_share", 1)
     out = {
         "metric": "FGMRES iterations/sec to 1e-8 residual, 3D Stokes-immersed (AL-preconditioned)",
         "value": outer / dt,
@@ -282,6 +306,7 @@ def main():
         # the whole solve again with the general-matrix SpMV kernel (no value dictionary anywhere):
         # the figure a matrix WITHOUT repeating entry values would get
         "general_matrix_leg": general,
+        "no_translate_sharing_leg": unshared,
     }
 
     # ----------------------------------------------------------- CPU baseline

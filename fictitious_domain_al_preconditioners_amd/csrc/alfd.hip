@@ -272,7 +272,7 @@ struct alfd_ctx {
   int win_RB_vi = 96;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
   int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
-  int vs_enable = 1, vs_NW = 4, vs_RB = 96, vs_xcd = 0;   // batch-major format (alfd_set_tunable "batch_major")
+  int vs_enable = 1, vs_NW = 4, vs_RB = 96, vs_xcd = 0, vs_share = 1;   // batch-major format (alfd_set_tunable "batch_major")
   std::vector<int64_t> rb_ptr[ALFD_NSLOTS + 1];   // row-block hint per slot (alfd_set_row_blocks)
   std::vector<int32_t> rb_rows[ALFD_NSLOTS + 1];
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
@@ -1993,7 +1993,7 @@ static bool vs_window(const std::vector<int32_t> &rows, const int64_t *rp, const
 // constant -- form SHARED batches (one stored template, a shift per row: what a uniform mesh gives for
 // the rows of one node type inside a brick); the rest form plain batches, longest rows first.
 static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, const int32_t *col, const double *val,
-                       const VsWindow &w, std::vector<VsBatch> &out) {
+                       const VsWindow &w, std::vector<VsBatch> &out, bool share = true) {
   const int nr = (int)rows.size();
   out.clear();
   std::vector<int64_t> len(nr);
@@ -2037,7 +2037,7 @@ static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, cons
       size_t g0 = 0;
       while (g0 < ids.size()) {
         size_t g1 = g0 + 1;
-        while (g1 < ids.size() && key[ids[g1]] == key[ids[g0]] && same(ids[g0], ids[g1])) ++g1;
+        while (share && g1 < ids.size() && key[ids[g1]] == key[ids[g0]] && same(ids[g0], ids[g1])) ++g1;
         size_t q = g0;
         while (g1 - q >= 2) {   // 2..8 rows per shared batch (never a lone leftover if it can be avoided)
           const size_t left = g1 - q;
@@ -2150,7 +2150,8 @@ static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val
 }
 
 static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int RB, int maxW,
-                    int GAP, int64_t nb_in, const int64_t *bptr_in, const int32_t *brows_in, VsPlan &pl) {
+                    int GAP, int64_t nb_in, const int64_t *bptr_in, const int32_t *brows_in, VsPlan &pl,
+                    bool share = true) {
   std::vector<int64_t> r_ptr;
   std::vector<int32_t> r_rows;
   if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, nb_in, bptr_in, brows_in, r_ptr, r_rows)) return;
@@ -2174,7 +2175,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
         for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
           rows.assign(brows + bptr[b], brows + bptr[b + 1]);
           if (rows.size() > (size_t)kVsMaxRows || !vs_window(rows, rp, col, GAP, maxW, w, nullptr, nullptr) ||
-              !vs_batches(rows, rp, col, val, w, batches[b])) {
+              !vs_batches(rows, rp, col, val, w, batches[b], share)) {
             bad = true;
             break;
           }
@@ -2532,9 +2533,9 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
     for (size_t i = 0; good && i + 1 < bp.size(); ++i) good = bp[i] <= bp[i + 1];
     if (!good) return ctx->err = "alfd_set_row_blocks: the blocks are not a partition of the matrix rows", ALFD_E_INVALID;
     plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, (int64_t)bp.size() - 1, bp.data(),
-            br.data(), pl);
+            br.data(), pl, ctx->vs_share != 0);
   } else {
-    plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pl);
+    plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pl, ctx->vs_share != 0);
   }
   if (!pl.ok) return ALFD_OK;
   DevCsr::Vs &v = m.vs;
@@ -4721,6 +4722,10 @@ int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value) {
   }
   if (std::strcmp(name, "batch_major") == 0) {   // takes effect at the next alfd_set_matrix
     ctx->vs_enable = value != 0;
+    return ALFD_OK;
+  }
+  if (std::strcmp(name, "batch_major_share") == 0) {   // 0: no template-shared batches (takes effect at the next alfd_set_matrix)
+    ctx->vs_share = value != 0;
     return ALFD_OK;
   }
   if (std::strcmp(name, "batch_major_waves") == 0) {

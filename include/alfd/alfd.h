@@ -434,7 +434,9 @@ int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_b
  *                  csrc/kernels_vs.hpp (decided at alfd_set_matrix; also switches the kernel at launch); 0: the
  *                  round-1 window formats.  "batch_major_rows" (4..250, default 96): rows per block of the long-row
  *                  form when no alfd_set_row_blocks hint is given; "batch_major_waves" (2, 4, 8): waves per workgroup;
- *                  "batch_major_xcd" (0/1): XCD-contiguous block order (measured slower).
+ *                  "batch_major_xcd" (0/1): XCD-contiguous block order (measured slower); "batch_major_share" (0/1):
+ *                  store rows that are translates of one another once (0: every row stored, ~3.1 B/nnz -- what a
+ *                  matrix with repeating values but no translate structure gets; at the next alfd_set_matrix).
  * Returns ALFD_E_INVALID for an unknown name. */
 int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value);
 /* Kernel-class timing of the last solve, accumulated with HIP events when

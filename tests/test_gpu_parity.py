@@ -53,7 +53,7 @@ def test_spmv_bitwise(ctxs, name, mode):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("blocks", ["runs", "bricks", "bricks444", "ragged", "rcb"])
+@pytest.mark.parametrize("blocks", ["runs", "bricks", "bricks444", "ragged", "rcb", "bricks_noshare"])
 def test_batch_major_format_bitwise(built, blocks):
     """The batch-major value-indexed format (kernels_vs.hpp, tunable batch_major): row blocks as runs of
     the numbering, as mesh bricks handed in through alfd_set_row_blocks, and as ragged random-size
@@ -67,6 +67,9 @@ def test_batch_major_format_bitwise(built, blocks):
         ctx.set_tunable("batch_major", 1)
         if blocks == "bricks":
             ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(big.params, (8, 2, 2)))
+        elif blocks == "bricks_noshare":            # every row stored: plain 4-row batches only
+            ctx.set_tunable("batch_major_share", 0)
+            ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(big.params, (16, 4, 1)))
         elif blocks == "bricks444":
             ctx.set_tunable("batch_major_waves", 8)
             ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(big.params, (4, 4, 4)))
@@ -81,7 +84,10 @@ def test_batch_major_format_bitwise(built, blocks):
         ctx.set_matrix(_abi.A, m)
         info = ctx.matrix_info(_abi.A)
         assert info["batch_major"] == (1 if blocks == "runs" else 2), info
-        assert info["streamed_bytes"] < (4.0 if blocks == "ragged" else 2.5) * m.nnz, info["streamed_bytes"] / m.nnz
+        if blocks == "bricks_noshare":
+            assert 3.0 * m.nnz < info["streamed_bytes"] < 3.8 * m.nnz
+        else:
+            assert info["streamed_bytes"] < (4.0 if blocks == "ragged" else 2.5) * m.nnz, info["streamed_bytes"] / m.nnz
         x = _rng_vec(m.ncols, 3)
         y0 = _rng_vec(m.nrows, 4)
         for mode in (0, 1):
