@@ -240,7 +240,7 @@ def test_rank_without_multiplier_rows(built):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_partitioned_batch_major_spmv_bitwise(built, world):
-    """The A-SpMV of a partition large enough for the LDS-window / batch-major formats (>= 2048 row blocks per
+    """The A-SpMV of a partition large enough for the LDS-window / batch-major formats (>= 512 row blocks per
     rank; the solves above are too small for them): halo columns inside the staged x windows, mesh-brick row
     blocks per rank.  Every rank's rows must equal the unpartitioned product bit for bit."""
     n, ref = 28 + 8 * (world - 2), 0

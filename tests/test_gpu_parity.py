@@ -178,7 +178,7 @@ def test_batch_major_short_rows_bitwise(built, kind):
 
 def test_spmv_every_kernel_family_bitwise(built):
     """Matrices that exercise each lanes-per-row kernel, the sparse-row form, the
-    streaming kernel and the LDS-windowed kernel (>= 2048 row blocks), incl.
+    streaming kernel and the LDS-windowed kernel (>= 512 row blocks), incl.
     ragged rows, empty rows and a single-entry row."""
     rng = np.random.default_rng(5)
     import scipy.sparse as sp
@@ -193,7 +193,7 @@ def test_spmv_every_kernel_family_bitwise(built):
     mats["sparse_rows"] = problems.Csr.from_scipy(a.tocsr())
     big = problems.generate(dim=3, degree=2, ncomp=3, n_cells=20, stokes=False, grad_div=True,
                             gamma_grad_div=10.0, radius=0.1, immersed_refine=0)
-    mats["windowed"] = big.mats["A"]       # 206763 rows >= 96*2048 -> LDS-windowed kernel
+    mats["windowed"] = big.mats["A"]       # 206763 rows >= 96*512 -> LDS-windowed kernel
     # value-indexed forms of the same matrix: 8-bit codes (as uploaded), 16-bit codes (every value
     # scaled by one of 9 factors: ~400 distinct per block) and raw blocks (40% unique values in the
     # first 30% of the rows); fully random values -> no dictionary
