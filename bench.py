@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--ml-smooth-ratio", type=float, default=256.0)
     ap.add_argument("--ml-coarse-degree", type=int, default=10)
     ap.add_argument("--agg-a", type=int, default=2, help="nodes per aggregate edge (geometric aggregation)")
-    ap.add_argument("--min-coarse", type=int, default=600, help="stop coarsening below this many unknowns")
+    ap.add_argument("--min-coarse", type=int, default=4000, help="stop coarsening below this many unknowns")
     ap.add_argument("--comm", choices=["rccl", "host"], default=os.environ.get("ALFD_BENCH_COMM", "rccl"),
                     help="multi-GPU transport: RCCL over xGMI (default) or host buffers through a gloo group "
                          "(alfd_comm_init_host; slower, for boxes where RCCL cannot start)")

@@ -155,7 +155,7 @@ def case(name):
         cfg.restart = 5
     elif name == "stokes3d_bench_settings":
         # exactly bench.py's solver settings (multigrid: Chebyshev(4) over [lmax/256, lmax], Chebyshev(10)
-        # coarsest solve, geometric aggregates a = 2 / min_coarse 600, inner cap 100 = prm:23) at small N
+        # coarsest solve, geometric aggregates a = 2 / min_coarse 4000, inner cap 100 = prm:23) at small N
         pb = problems.stokes3d_sphere(8, 1)
         cfg = _abi.default_config(_abi.AL_STOKES)
         cfg.inner_prec = _abi.PREC_MULTILEVEL
@@ -172,8 +172,8 @@ def aggregates_of(pb, cfg):
     """Aggregates handed to both the library and the oracle for ALFD_PREC_MULTILEVEL."""
     if cfg.inner_prec != _abi.PREC_MULTILEVEL:
         return None
-    if cfg.ml_coarse_degree == 10:      # stokes3d_bench_settings: bench.py's --agg-a 2 --min-coarse 600
-        return problems.geometric_aggregates(pb, a=2, min_coarse=600)
+    if cfg.ml_coarse_degree == 10:      # stokes3d_bench_settings: bench.py's --agg-a 2 --min-coarse 4000
+        return problems.geometric_aggregates(pb, a=2, min_coarse=4000)
     return problems.geometric_aggregates(pb, a=2, min_coarse=100)
 
 
