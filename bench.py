@@ -74,9 +74,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solver has no CPU path")
+    if os.environ.get("ALFD_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0          # rehearsal of the N > 1 code path on a one-GPU box (with --comm host): all ranks on cuda:0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # control plane (unique-id broadcast, barriers, max over ranks of the timing) over gloo on CPU tensors; the data
+        # path -- halo exchanges and reductions inside libalfd -- is RCCL (or the host transport with --comm host)
+        dist.init_process_group("gloo")
 
     def barrier():
         if world > 1:
@@ -110,7 +114,7 @@ def main():
     ctx = solver.Context(local_rank)
     if world > 1:
         if args.comm == "host":
-            ctx.comm_init_torch(dist.new_group(backend="gloo"))
+            ctx.comm_init_torch(dist.group.WORLD)
         else:
             uid = [solver.Context.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
@@ -155,14 +159,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     tim = ctx.timing()
     ctx.enable_timing(False)
     nnz_A_global = int(pb.mats["A"].nnz)
     if world > 1:
-        tn = torch.tensor([nnz_A_global], dtype=torch.int64, device="cuda")
+        tn = torch.tensor([nnz_A_global], dtype=torch.int64)
         dist.all_reduce(tn)
         nnz_A_global = int(tn.item())
 
