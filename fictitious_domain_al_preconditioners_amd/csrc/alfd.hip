@@ -275,6 +275,7 @@ struct alfd_ctx {
   int vs_enable = 1, vs_NW = 4, vs_RB = 96, vs_xcd = 0, vs_share = 1;   // batch-major format (alfd_set_tunable "batch_major")
   std::vector<int64_t> rb_ptr[ALFD_NSLOTS + 1];   // row-block hint per slot (alfd_set_row_blocks)
   std::vector<int32_t> rb_rows[ALFD_NSLOTS + 1];
+  int win_short_min_blocks = 256;           // the same for short-row matrices (ALFD_SPMV_WINDOW_SHORT_MIN_BLOCKS; 64 costs cfg 3 30 %, 1024 leaves its 262 k-row level operator out)
   int win_min_blocks = 512;                 // long-row window formats need this many row blocks (ALFD_SPMV_WINDOW_MIN_BLOCKS; 2 per CU: the level-2 operator of the bench, 152 k rows, gains 2 % of the solve)
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
   int64_t ntot() const { return off[nblocks]; }
@@ -2733,7 +2734,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
   // enough row blocks to fill the chip (256 CUs x several workgroups)
   const bool win_long = m.L == 64 && m.nrows >= (int64_t)ctx->win_RB * ctx->win_min_blocks;
   const bool win_short = ctx->win_short_scale > 0 && m.L >= 8 && m.L < 64 &&
-                         m.nrows >= (int64_t)std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / m.L) * 1024;
+                         m.nrows >= (int64_t)std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / m.L) * ctx->win_short_min_blocks;
   if (ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0)
     RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot));
   if (ctx->vs_enable && m.vi && m.L == 64) RC(build_vs(ctx, m, slot, rp, col_up, val));
@@ -3828,6 +3829,7 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW")) ctx->win_enable = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB")) ctx->win_RB = std::max(4, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MIN_BLOCKS")) ctx->win_min_blocks = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("ALFD_SPMV_WINDOW_SHORT_MIN_BLOCKS")) ctx->win_short_min_blocks = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
   if (const char *e = std::getenv("ALFD_ML_REPLICATE")) ctx->ml_rep_threshold = std::atoll(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_LEVELS")) ctx->vi_levels = std::atoi(e);
