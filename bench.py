@@ -47,9 +47,17 @@ def main():
                     help="extra timed solves with the dictionary-free 10 B/nnz SpMV kernel (0 = skip)")
     ap.add_argument("--inner-prec", choices=["chebyshev", "multilevel"],
                     default=os.environ.get("ALFD_BENCH_PREC", "multilevel"))
-    ap.add_argument("--ml-smooth-degree", type=int, default=4)
-    ap.add_argument("--ml-smooth-ratio", type=float, default=256.0)
+    ap.add_argument("--hierarchy", choices=["geometric", "aggregation"], default=os.environ.get("ALFD_BENCH_HIERARCHY", "geometric"),
+                    help="multigrid transfers: CSR prolongators (Q2 -> Q1 embedding, then trilinear interpolation; "
+                         "alfd_set_prolongator) or piecewise-constant aggregates (round 2; the only one on several ranks)")
+    ap.add_argument("--ml-smooth-degree", type=int, default=None, help="default 3 (geometric) / 4 (aggregation)")
+    ap.add_argument("--ml-smooth-degree-coarse", type=int, default=None,
+                    help="smoother degree on levels >= 1 (default 5 with the geometric hierarchy, else the fine one)")
+    ap.add_argument("--ml-smooth-ratio", type=float, default=None, help="default 30 (geometric) / 256 (aggregation)")
     ap.add_argument("--ml-coarse-degree", type=int, default=10)
+    ap.add_argument("--patch-degree", type=int, default=20, help="interface-patch Chebyshev degree (geometric hierarchy; 0 = off)")
+    ap.add_argument("--patch-ratio", type=float, default=400.0)
+    ap.add_argument("--coarse-direct", type=int, default=1024, help="explicit coarsest inverse up to this many unknowns (geometric hierarchy)")
     ap.add_argument("--agg-a", type=int, default=2, help="nodes per aggregate edge (geometric aggregation)")
     ap.add_argument("--min-coarse", type=int, default=4000, help="stop coarsening below this many unknowns")
     ap.add_argument("--comm", choices=["rccl", "host"], default=os.environ.get("ALFD_BENCH_COMM", "rccl"),
@@ -105,10 +113,16 @@ def main():
     cfg.inner.max_steps = args.inner_max
     cfg.log_level = int(os.environ.get("ALFD_BENCH_LOG_LEVEL", "0"))
     aggregates = levels = None
+    geometric = args.hierarchy == "geometric" and world == 1      # CSR prolongators are single-rank for now
     if args.inner_prec == "multilevel":
         cfg.inner_prec = _abi.PREC_MULTILEVEL
-        cfg.ml_smooth_degree, cfg.ml_smooth_ratio = args.ml_smooth_degree, args.ml_smooth_ratio
+        cfg.ml_smooth_degree = args.ml_smooth_degree if args.ml_smooth_degree is not None else (3 if geometric else 4)
+        cfg.ml_smooth_degree_coarse = (args.ml_smooth_degree_coarse if args.ml_smooth_degree_coarse is not None
+                                       else (5 if geometric else 0))
+        cfg.ml_smooth_ratio = args.ml_smooth_ratio if args.ml_smooth_ratio is not None else (30.0 if geometric else 256.0)
         cfg.ml_coarse_degree = args.ml_coarse_degree
+        if geometric:
+            cfg.ml_patch_degree, cfg.ml_patch_ratio, cfg.ml_coarse_direct = args.patch_degree, args.patch_ratio, args.coarse_direct
 
     t0 = time.time()
     ctx = solver.Context(local_rank)
@@ -120,7 +134,11 @@ def main():
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(rank, world, uid[0])
         ctx.set_partition(plan.offsets)
-    if cfg.inner_prec == _abi.PREC_MULTILEVEL:
+    if cfg.inner_prec == _abi.PREC_MULTILEVEL and geometric:
+        ta = time.time()
+        levels = aggregates = problems.tensor_prolongators(pb.params, min_coarse=min(args.min_coarse, max(args.coarse_direct, 100)))
+        log(f"prolongators: levels {[lv[1] for lv in levels]} in {time.time()-ta:.1f} s")
+    elif cfg.inner_prec == _abi.PREC_MULTILEVEL:
         ta = time.time()
         levels = partition.partitioned_geometric_aggregates(pb.params, plan, a=args.agg_a, min_coarse=args.min_coarse)   # slab-respecting boxes
         aggregates = partition.local_aggregates(levels, rank)
@@ -277,6 +295,11 @@ def main():
             "dof_iterations_per_s": ntot * outer / dt,
             "final_residual": last.last_residual, "initial_residual": last.initial_residual,
             "inner_prec": (f"chebyshev({cfg.cheb_degree})-jacobi" if cfg.inner_prec == _abi.PREC_CHEBYSHEV else
+                           f"geometric multigrid (Q2->Q1 embedding + trilinear prolongators, Galerkin), V-cycle with "
+                           f"chebyshev({cfg.ml_smooth_degree})/{cfg.ml_smooth_ratio:g} smoothing (degree {cfg.ml_smooth_degree_coarse or cfg.ml_smooth_degree} below the fine level), interface-patch "
+                           f"chebyshev({cfg.ml_patch_degree})/{cfg.ml_patch_ratio:g} corrections, "
+                           f"{'explicit inverse' if cfg.ml_coarse_direct >= levels[-1][1] else f'chebyshev({cfg.ml_coarse_degree})'} "
+                           f"on the coarsest level, levels {[lv[1] for lv in levels]}" if geometric else
                            f"aggregation-multigrid V-cycle, chebyshev({cfg.ml_smooth_degree}) smoothing, "
                            f"chebyshev({cfg.ml_coarse_degree}) coarsest solve, "
                            f"levels {[lv[1] for lv in levels]}"),

@@ -57,7 +57,8 @@ class Config(C.Structure):
         ("ml_smooth_ratio", C.c_double), ("ml_coarse_ratio", C.c_double),
         ("aug_assembled", C.c_int32), ("w_inverse", C.c_int32),
         ("mass", Control),
-        ("fgmres_flavour", C.c_int32), ("reserved0", C.c_int32),
+        ("fgmres_flavour", C.c_int32), ("ml_smooth_degree_coarse", C.c_int32),
+        ("ml_patch_degree", C.c_int32), ("ml_coarse_direct", C.c_int32), ("ml_patch_ratio", C.c_double),
     ]
 
 
@@ -129,4 +130,5 @@ def default_config(variant=AL_STOKES) -> Config:
     c.ml_smooth_ratio, c.ml_coarse_ratio = 4.0, 400.0
     c.w_inverse = W_DIAGONAL
     c.mass = Control(CTRL_REDUCTION, 1000, 1e-30, 1e-14)
+    c.ml_patch_degree, c.ml_coarse_direct, c.ml_patch_ratio = 0, 0, 30.0
     return c

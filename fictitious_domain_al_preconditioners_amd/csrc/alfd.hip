@@ -28,6 +28,7 @@
 #include <memory>
 #include <climits>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -229,6 +230,18 @@ struct alfd_ctx {
   std::vector<int32_t> ml_agg[ALFD_MAX_LEVELS];
   std::vector<double> ml_wgt[ALFD_MAX_LEVELS];
   int64_t ml_ncoarse[ALFD_MAX_LEVELS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HostCsr ml_P[ALFD_MAX_LEVELS];               // CSR prolongator of a level (alfd_set_prolongator), replaces its aggregates
+  DevCsr ml_inv;                               // explicit inverse of the coarsest operator (alfd_config::ml_coarse_direct)
+  // interface patch (alfd_config::ml_patch_degree > 0): S = non-empty rows of Ct, vectors of length |S|
+  struct Patch {
+    bool on = false;
+    int64_t m = 0, mpad = 0;
+    DevCsr Ass, As, Ats, Cs, Cts;              // A[S,S], A[S,:], A[:,S] (sparse rows), C[:,S], Ct[S,:]
+    int32_t *S = nullptr;
+    double *dinv = nullptr, *rS = nullptr, *zS = nullptr, *uS = nullptr, *eS = nullptr, *cd = nullptr,
+           *cres = nullptr, *ctmp = nullptr, *rr = nullptr;
+    double lmax = 0;
+  } patch;
   std::vector<MlLevel> ml;
   int ml_rep_level = -1;                      // first replicated level (multi-rank), -1: none
   int64_t ml_rep_threshold = 300000;          // replicate levels with at most this many unknowns (ALFD_ML_REPLICATE)
@@ -899,13 +912,14 @@ static int cheb_apply(alfd_ctx *ctx, int op, const double *r, double *z, int64_t
 // deal.II SolverCG via inverse_operator (zero initial guess) [EXT]; b and x are
 // padded device vectors of the operator's span.
 static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z);
+static int ml_apply(alfd_ctx *ctx, const double *r, double *z);
 static int pcg(alfd_ctx *ctx, int op, int prec, const alfd_control &ctrl, const double *b, double *x,
                int *its_out, State *st_out, double *res_out) {
   const int64_t npad = op_npad(ctx, op);
   const int64_t nb = npad / kChunk;
   const double *dinv = op_dinv(ctx, op);
   double *r = ctx->w_r, *z = ctx->w_z, *p = ctx->w_p, *Ap = ctx->w_Ap;
-  HIPC(hipMemcpyAsync(r, b, npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  VEC_LAUNCH(scale_copy_kernel, npad, 16, 1.0, b, r);   // r = b
   HIPC(hipMemsetAsync(x, 0, npad * sizeof(double), ctx->stream));
   // SpMV writes rows only: the padding of Ap may hold data of a previous, longer
   // solve and must be zero for the fused r-update / dot kernels.
@@ -926,7 +940,7 @@ static int pcg(alfd_ctx *ctx, int op, int prec, const alfd_control &ctrl, const 
       VEC_LAUNCH(jacobi_dot_kernel, npad, 24, dinv, r, z, ctx->partial);
       RC(finish_dots(ctx, nb, 1, 0, FIN_RZ));
     } else if (prec == ALFD_PREC_MULTILEVEL && op == OP_AUG) {
-      RC(ml_cycle(ctx, 0, r, z));
+      RC(ml_apply(ctx, r, z));
       RC(dot_async(ctx, npad, r, z, 0, FIN_RZ));
     } else {
       RC(cheb_apply(ctx, op, r, z, npad));
@@ -1135,8 +1149,7 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
   if (c.variant == ALFD_AL2) {
     // augmented_lagrangian_preconditioner.h:28-34
     RC(winv_scale(ctx, -c.gamma, u + off[1], v + off[1]));
-    HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
-                        ctx->stream));
+    VEC_LAUNCH(scale_copy_kernel, n0p, 16, 1.0, u + off[0], ctx->rhs_tmp);
     RC(spmv(ctx, ALFD_CT, v + off[1], ctx->rhs_tmp, 1, -1.0));
     return inner_solve(ctx, OP_AUG, ctx->rhs_tmp, v + off[0]);
   }
@@ -1147,8 +1160,7 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
     RC(winv_scale(ctx, sgn * c.gamma, u + off[2], v + off[2]));
     RC(inner_solve(ctx, OP_MP, u + off[1], ctx->q_tmp));
     VEC_LAUNCH(scale_copy_kernel, n1p, 16, sgn * c.gamma_grad_div, ctx->q_tmp, v + off[1]);
-    HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
-                        ctx->stream));
+    VEC_LAUNCH(scale_copy_kernel, n0p, 16, 1.0, u + off[0], ctx->rhs_tmp);
     if (tri) {
       RC(spmv(ctx, ALFD_BT, v + off[1], ctx->rhs_tmp, 1, -1.0));
       RC(spmv(ctx, ALFD_CT, v + off[2], ctx->rhs_tmp, 1, -1.0));
@@ -1168,8 +1180,7 @@ static int precond_apply(alfd_ctx *ctx, const double *u, double *v) {
     } else {
       RC(spmv(ctx, ALFD_M, d1, ctx->t_lam, 2, 0.0, w));
     }
-    HIPC(hipMemcpyAsync(ctx->rhs_tmp, u + off[0], n0p * sizeof(double), hipMemcpyDeviceToDevice,
-                        ctx->stream));
+    VEC_LAUNCH(scale_copy_kernel, n0p, 16, 1.0, u + off[0], ctx->rhs_tmp);
     RC(spmv(ctx, ALFD_CT, ctx->t_lam, ctx->rhs_tmp, 1, c.gamma));               // u + gamma Ct t
     RC(spmv(ctx, ALFD_CT, d2, ctx->rhs_tmp, 1, -1.0));                          //   - Ct d2
     return inner_solve(ctx, OP_AUG, ctx->rhs_tmp, d0);                          // d0 = A11_inv (...)
@@ -2855,6 +2866,9 @@ static void free_levels(alfd_ctx *ctx) {
   for (MlLevel &L : ctx->ml)
     for (DevCsr *m : {&L.A, &L.C, &L.Ct, &L.P, &L.R, &L.gA, &L.gC, &L.gCt, &L.gP, &L.gR}) csr_free(*m);
   ctx->ml.clear();
+  csr_free(ctx->ml_inv);
+  for (DevCsr *m : {&ctx->patch.Ass, &ctx->patch.As, &ctx->patch.Ats, &ctx->patch.Cs, &ctx->patch.Cts}) csr_free(*m);
+  ctx->patch = alfd_ctx::Patch();   // its vectors belong to the setup workspace
   ctx->ml_rep_level = -1;
 }
 
@@ -3047,7 +3061,8 @@ static int ml_cycle_rep(alfd_ctx *ctx, int l, const double *r, double *z) {
   const int last = (int)ctx->ml.size() - 1;
   if (l == last) return level_cheb_rep(ctx, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
   MlLevel &L = ctx->ml[l], &N = ctx->ml[l + 1];
-  RC(level_cheb_rep(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, r, z));
+  const int sdeg = l > 0 && c.ml_smooth_degree_coarse > 0 ? c.ml_smooth_degree_coarse : c.ml_smooth_degree;
+  RC(level_cheb_rep(ctx, l, sdeg, c.ml_smooth_ratio, r, z));
   RC(level_op_rep(ctx, l, z, L.gt));
   VEC_LAUNCH(sub_from_kernel, L.gnpad, 24, r, L.gt);
   RC(spmv_m(ctx, N.gR, ALFD_T_SPMV_OTHER, L.gt, N.gr, 0));
@@ -3055,7 +3070,7 @@ static int ml_cycle_rep(alfd_ctx *ctx, int l, const double *r, double *z) {
   RC(spmv_m(ctx, N.gP, ALFD_T_SPMV_OTHER, N.gz, z, 1, 1.0));
   RC(level_op_rep(ctx, l, z, L.gt));
   VEC_LAUNCH(sub_from_kernel, L.gnpad, 24, r, L.gt);
-  RC(level_cheb_rep(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, L.gt, L.gr));
+  RC(level_cheb_rep(ctx, l, sdeg, c.ml_smooth_ratio, L.gt, L.gr));
   VEC_LAUNCH(axpy_kernel, L.gnpad, 24, (const double *)nullptr, 0, 1.0, L.gr, z);
   HIPC(hipGetLastError());
   return ALFD_OK;
@@ -3065,9 +3080,13 @@ static int ml_cycle_rep(alfd_ctx *ctx, int l, const double *r, double *z) {
 static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z) {
   const alfd_config &c = ctx->cfg;
   const int last = (int)ctx->ml.size() - 1;
-  if (l == last) return level_cheb(ctx, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  if (l == last) {
+    if (ctx->ml_inv.present) return spmv_m(ctx, ctx->ml_inv, ALFD_T_SPMV_OTHER, r, z, 0);   // z = Aug_c^-1 r
+    return level_cheb(ctx, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  }
   MlLevel &L = ctx->ml[l], &N = ctx->ml[l + 1];
-  RC(level_cheb(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, r, z));       // pre-smoothing from zero
+  const int sdeg = l > 0 && c.ml_smooth_degree_coarse > 0 ? c.ml_smooth_degree_coarse : c.ml_smooth_degree;
+  RC(level_cheb(ctx, l, sdeg, c.ml_smooth_ratio, r, z));                     // pre-smoothing from zero
   RC(level_op(ctx, l, z, L.t));
   VEC_LAUNCH(sub_from_kernel, L.npad, 24, r, L.t);                           // t = r - Aug z
   RC(spmv_m(ctx, N.R, ALFD_T_SPMV_OTHER, L.t, N.r, 0));                      // r_c = P^T t
@@ -3089,13 +3108,314 @@ static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z) {
   }
   RC(level_op(ctx, l, z, L.t));
   VEC_LAUNCH(sub_from_kernel, L.npad, 24, r, L.t);
-  RC(level_cheb(ctx, l, c.ml_smooth_degree, c.ml_smooth_ratio, L.t, L.r));   // post-smoothing correction
+  RC(level_cheb(ctx, l, sdeg, c.ml_smooth_ratio, L.t, L.r));                 // post-smoothing correction
   VEC_LAUNCH(axpy_kernel, L.npad, 24, (const double *)nullptr, 0, 1.0, L.r, z);
   HIPC(hipGetLastError());
   return ALFD_OK;
 }
 
 static int ws_alloc_zero(alfd_ctx *ctx, double **p, int64_t count);
+
+// ---- interface patch (alfd_config::ml_patch_degree): y = Aug_SS x on patch-compact vectors
+static int patch_op(alfd_ctx *ctx, const double *x, double *y) {
+  alfd_ctx::Patch &Q = ctx->patch;
+  RC(spmv_m(ctx, Q.Ass, ALFD_T_SPMV_OTHER, x, y, 0));
+  if (ctx->cfg.aug_assembled) return ALFD_OK;
+  RC(spmv_m(ctx, Q.Cs, ALFD_T_SPMV_OTHER, x, ctx->t_lam, 2, 0.0, ctx->diag[ALFD_INVW]));
+  return spmv_m(ctx, Q.Cts, ALFD_T_SPMV_OTHER, ctx->t_lam, y, 1, ctx->cfg.gamma);
+}
+
+// z = q(D^-1 Aug_SS) D^-1 r, q = Chebyshev polynomial of degree ml_patch_degree (zero start)
+static int patch_cheb(alfd_ctx *ctx, const double *r, double *z) {
+  alfd_ctx::Patch &Q = ctx->patch;
+  const int degree = ctx->cfg.ml_patch_degree;
+  const double lmax = Q.lmax, lmin = lmax / ctx->cfg.ml_patch_ratio;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  VEC_LAUNCH(cheb_init_kernel, Q.mpad, degree > 1 ? 40 : 32, 1.0 / theta, Q.dinv, r, Q.cd, z, Q.cres, degree > 1 ? 1 : 0);
+  for (int j = 1; j < degree; ++j) {
+    RC(patch_op(ctx, Q.cd, Q.ctmp));
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    VEC_LAUNCH(cheb_step_kernel, Q.mpad, 64, c1, c2, Q.dinv, Q.ctmp, Q.cres, Q.cd, z);
+    rho = rho_new;
+  }
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+// The multilevel inner preconditioner: the V-cycle, wrapped (ml_patch_degree > 0) into two corrections on the
+// interface patch:  z1 = E q E^T r;  z2 = z1 + V(r - Aug z1);  z = z2 + E q E^T (r - Aug z2)  -- symmetric.
+static int ml_apply(alfd_ctx *ctx, const double *r, double *z) {
+  alfd_ctx::Patch &Q = ctx->patch;
+  if (!Q.on) return ml_cycle(ctx, 0, r, z);
+  const int64_t n0p = pad_chunk(ctx->n[0]);
+  const unsigned gm = (unsigned)((Q.m + 255) / 256);
+  const bool pen = !ctx->cfg.aug_assembled;
+  const double *w = ctx->diag[ALFD_INVW];
+  hipLaunchKernelGGL(gather_kernel, dim3(gm), dim3(256), 0, ctx->stream, Q.m, Q.S, r, Q.rS);
+  RC(patch_cheb(ctx, Q.rS, Q.zS));
+  VEC_LAUNCH(scale_copy_kernel, n0p, 16, 1.0, r, Q.rr);                           // rr = r (a blit copy costs 10x this kernel)
+  RC(spmv_m(ctx, Q.Ats, ALFD_T_SPMV_OTHER, Q.zS, Q.rr, 1, -1.0));                 // rr -= A[:,S] zS
+  if (pen) {
+    RC(spmv_m(ctx, Q.Cs, ALFD_T_SPMV_OTHER, Q.zS, ctx->t_lam, 2, 0.0, w));
+    RC(spmv(ctx, ALFD_CT, ctx->t_lam, Q.rr, 1, -ctx->cfg.gamma));                 // rr -= gamma Ct W^-1 C[:,S] zS
+  }
+  RC(ml_cycle(ctx, 0, Q.rr, z));
+  hipLaunchKernelGGL(scatter_add_kernel, dim3(gm), dim3(256), 0, ctx->stream, Q.m, Q.S, Q.zS, z);
+  RC(spmv_m(ctx, Q.As, ALFD_T_SPMV_OTHER, z, Q.uS, 0));                           // (Aug z) on S
+  if (pen) {
+    RC(spmv(ctx, ALFD_C, z, ctx->t_lam, 2, 0.0, w));
+    RC(spmv_m(ctx, Q.Cts, ALFD_T_SPMV_OTHER, ctx->t_lam, Q.uS, 1, ctx->cfg.gamma));
+  }
+  VEC_LAUNCH(sub_from_kernel, Q.mpad, 24, Q.rS, Q.uS);                            // uS = r_S - (Aug z)_S
+  RC(patch_cheb(ctx, Q.uS, Q.eS));
+  hipLaunchKernelGGL(scatter_add_kernel, dim3(gm), dim3(256), 0, ctx->stream, Q.m, Q.S, Q.eS, z);
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
+// out = A * Pm on the host, multi-threaded over row ranges.  Every output entry (i, J) is ONE sequential fma
+// chain: entries k of row i of A in CSR order, entries of row col_k of Pm in CSR order,
+// acc_J = fma(a_ik, p_kJ, acc_J) from 0; the finished row is sorted by column (the oracle repeats this).
+static void spgemm_host(const HostCsr &A, const HostCsr &Pm, HostCsr &out) {
+  const int64_t nrows = A.nrows, nc = Pm.ncols;
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                                           (nrows + 4095) / 4096));
+  std::vector<std::vector<int32_t>> t_cnt(T), t_col(T);
+  std::vector<std::vector<double>> t_val(T);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() {
+      const int64_t i0 = nrows * t / T, i1 = nrows * (t + 1) / T;
+      std::vector<int64_t> stamp(nc, -1);
+      std::vector<double> acc(nc, 0.0);
+      std::vector<int32_t> touched;
+      t_cnt[t].reserve(i1 - i0);
+      for (int64_t i = i0; i < i1; ++i) {
+        touched.clear();
+        for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+          const double a = A.val[k];
+          const int64_t j = A.col[k];
+          for (int64_t e = Pm.rp[j]; e < Pm.rp[j + 1]; ++e) {
+            const int32_t J = Pm.col[e];
+            if (stamp[J] != i) {
+              stamp[J] = i;
+              acc[J] = std::fma(a, Pm.val[e], 0.0);
+              touched.push_back(J);
+            } else {
+              acc[J] = std::fma(a, Pm.val[e], acc[J]);
+            }
+          }
+        }
+        std::sort(touched.begin(), touched.end());
+        t_cnt[t].push_back((int32_t)touched.size());
+        for (int32_t J : touched) {
+          t_col[t].push_back(J);
+          t_val[t].push_back(acc[J]);
+        }
+      }
+    });
+  for (auto &x : th) x.join();
+  out.nrows = nrows;
+  out.ncols = nc;
+  out.rp.assign(1, 0);
+  out.rp.reserve(nrows + 1);
+  int64_t total = 0;
+  for (int t = 0; t < T; ++t) total += (int64_t)t_col[t].size();
+  out.col.clear();
+  out.val.clear();
+  out.col.reserve(total);
+  out.val.reserve(total);
+  for (int t = 0; t < T; ++t) {
+    for (int32_t c : t_cnt[t]) out.rp.push_back(out.rp.back() + c);
+    out.col.insert(out.col.end(), t_col[t].begin(), t_col[t].end());
+    out.val.insert(out.val.end(), t_val[t].begin(), t_val[t].end());
+    std::vector<int32_t>().swap(t_col[t]);
+    std::vector<double>().swap(t_val[t]);
+  }
+}
+
+// rows `rows` of A with compact row numbering (full_rows = 0) or as rows of an nrows_out-row matrix whose other
+// rows are empty (full_rows = 1); columns kept where colmap[col] >= 0 (renumbered) or all (colmap == nullptr)
+static void extract_host(const HostCsr &A, const std::vector<int32_t> &rows, const int32_t *colmap, int64_t ncols,
+                         bool full_rows, HostCsr &out) {
+  out.nrows = full_rows ? A.nrows : (int64_t)rows.size();
+  out.ncols = ncols;
+  out.rp.assign(out.nrows + 1, 0);
+  out.col.clear();
+  out.val.clear();
+  int64_t next = 0;   // next output row to close
+  for (size_t q = 0; q < rows.size(); ++q) {
+    const int64_t i = rows[q], orow = full_rows ? i : (int64_t)q;
+    for (; next <= orow; ++next) out.rp[next] = (int64_t)out.col.size();
+    for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+      const int32_t c = colmap ? colmap[A.col[k]] : A.col[k];
+      if (c < 0) continue;
+      out.col.push_back(c);
+      out.val.push_back(A.val[k]);
+    }
+  }
+  for (; next <= out.nrows; ++next) out.rp[next] = (int64_t)out.col.size();
+}
+
+static int upload_level(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h);
+static int level_op(alfd_ctx *ctx, int l, const double *x, double *y);
+
+// S, the patch operators and lambda_max(D^-1 Aug_SS); A / C / Ct are the host copies of the level-0 operators
+static int patch_setup(alfd_ctx *ctx, const HostCsr &A, const HostCsr &C, const HostCsr &Ct) {
+  alfd_ctx::Patch &Q = ctx->patch;
+  const alfd_config &c = ctx->cfg;
+  const int64_t n = ctx->n[0];
+  std::vector<int32_t> S, Trows, pos(n, -1);
+  for (int64_t i = 0; i < n; ++i)
+    if (Ct.rp[i + 1] > Ct.rp[i]) {
+      pos[i] = (int32_t)S.size();
+      S.push_back((int32_t)i);
+    }
+  const int64_t m = (int64_t)S.size();
+  if (m == 0) return ALFD_OK;
+  {
+    // rows of A with a column in S (the rows E^T-corrections reach): scanned in parallel, kept in order
+    const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<int32_t>> part(T);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+          bool hit = false;
+          for (int64_t k = A.rp[i]; k < A.rp[i + 1] && !hit; ++k) hit = pos[A.col[k]] >= 0;
+          if (hit) part[t].push_back((int32_t)i);
+        }
+      });
+    for (auto &x : th) x.join();
+    for (auto &v : part) Trows.insert(Trows.end(), v.begin(), v.end());
+  }
+  std::vector<int32_t> lam_rows(C.nrows);
+  for (int64_t k = 0; k < C.nrows; ++k) lam_rows[k] = (int32_t)k;
+  HostCsr h;
+  extract_host(A, S, pos.data(), m, false, h);
+  RC(upload_level(ctx, Q.Ass, h));
+  extract_host(A, S, nullptr, n, false, h);
+  RC(upload_level(ctx, Q.As, h));
+  extract_host(A, Trows, pos.data(), m, true, h);
+  RC(upload_level(ctx, Q.Ats, h));
+  extract_host(C, lam_rows, pos.data(), m, false, h);
+  RC(upload_level(ctx, Q.Cs, h));
+  extract_host(Ct, S, nullptr, Ct.ncols, false, h);
+  RC(upload_level(ctx, Q.Cts, h));
+  Q.m = m;
+  Q.mpad = pad_chunk(m);
+  void *q = nullptr;
+  HIPC(hipMalloc(&q, m * sizeof(int32_t)));
+  ctx->ws_allocs.push_back(q);
+  Q.S = static_cast<int32_t *>(q);
+  HIPC(hipMemcpyAsync(Q.S, S.data(), m * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  for (double **v : {&Q.dinv, &Q.rS, &Q.zS, &Q.uS, &Q.eS, &Q.cd, &Q.cres, &Q.ctmp}) RC(ws_alloc_zero(ctx, v, Q.mpad));
+  RC(ws_alloc_zero(ctx, &Q.rr, pad_chunk(n)));
+  const unsigned gm = (unsigned)((m + 255) / 256);
+  hipLaunchKernelGGL(gather_kernel, dim3(gm), dim3(256), 0, ctx->stream, m, Q.S, ctx->dinv_aug, Q.dinv);
+  // lambda_max(D^-1 Aug_SS): power iteration from the integer-hash vector (patch-compact index)
+  double *v = Q.rS, *wv = Q.zS;
+  hipLaunchKernelGGL(hash_vector_kernel, dim3(gm), dim3(256), 0, ctx->stream, m, (int64_t)0, v);
+  double lam = 0;
+  for (int it = 0; it < c.cheb_power_its; ++it) {
+    RC(dot_async(ctx, Q.mpad, v, v, S_TMP));
+    RC(read_scalars(ctx, S_TMP, 1));
+    VEC_LAUNCH(scale_kernel, Q.mpad, 16, (const double *)nullptr, 0, 0, 1.0 / std::sqrt(ctx->sc_host[S_TMP]), v);
+    RC(patch_op(ctx, v, wv));
+    VEC_LAUNCH(pmul_scale_kernel, Q.mpad, 24, 1.0, Q.dinv, wv, wv);
+    RC(dot_async(ctx, Q.mpad, wv, wv, S_TMP));
+    RC(read_scalars(ctx, S_TMP, 1));
+    lam = std::sqrt(ctx->sc_host[S_TMP]);
+    std::swap(v, wv);
+  }
+  Q.lmax = lam * c.cheb_safety;
+  HIPC(hipMemsetAsync(Q.rS, 0, Q.mpad * sizeof(double), ctx->stream));
+  HIPC(hipMemsetAsync(Q.zS, 0, Q.mpad * sizeof(double), ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  Q.on = true;
+  if (c.log_level > 0 && ctx->rank == 0)
+    std::fprintf(stderr, "[alfd] interface patch: %lld rows, A[S,S] %lld nnz, %lld rows of A touch it, lambda_max %.3f\n",
+                 (long long)m, (long long)Q.Ass.nnz, (long long)Trows.size(), Q.lmax);
+  return ALFD_OK;
+}
+
+// Explicit inverse of the coarsest Aug_c = A_c + gamma Ct_c W^-1 C_c: dense Cholesky on the host, every entry a
+// sequential fma chain (the oracle repeats the loops), uploaded as a dense CSR so that z = Aug_c^-1 r runs in
+// the canonical SpMV order.  ML solves its coarsest level directly as well (KLU, utilities.h:304-317).
+static int coarse_inverse(alfd_ctx *ctx, const HostCsr &A, const HostCsr &C, const HostCsr &Ct, const std::vector<double> &w) {
+  const int64_t n = A.nrows;
+  std::vector<double> D((size_t)n * n, 0.0);
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) D[i * n + A.col[k]] = A.val[k];
+  if (!ctx->cfg.aug_assembled)
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t k = Ct.rp[i]; k < Ct.rp[i + 1]; ++k) {
+        const int64_t lam = Ct.col[k];
+        const double sfac = (ctx->cfg.gamma * w[lam]) * Ct.val[k];
+        for (int64_t e = C.rp[lam]; e < C.rp[lam + 1]; ++e)
+          D[i * n + C.col[e]] = std::fma(sfac, C.val[e], D[i * n + C.col[e]]);
+      }
+  const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  auto par_for = [&](int64_t lo, int64_t hi, const std::function<void(int64_t)> &body) {
+    if (hi - lo < 256) {
+      for (int64_t i = lo; i < hi; ++i) body(i);
+      return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        for (int64_t i = lo + (hi - lo) * t / T; i < lo + (hi - lo) * (t + 1) / T; ++i) body(i);
+      });
+    for (auto &x : th) x.join();
+  };
+  for (int64_t j = 0; j < n; ++j) {
+    double d = D[j * n + j];
+    for (int64_t k = 0; k < j; ++k) d = std::fma(-D[j * n + k], D[j * n + k], d);
+    if (!(d > 0.0)) return ctx->err = "coarsest multigrid operator is not positive definite", ALFD_E_BREAKDOWN;
+    const double ljj = std::sqrt(d);
+    D[j * n + j] = ljj;
+    par_for(j + 1, n, [&](int64_t i) {
+      double sacc = D[i * n + j];
+      for (int64_t k = 0; k < j; ++k) sacc = std::fma(-D[i * n + k], D[j * n + k], sacc);
+      D[i * n + j] = sacc / ljj;
+    });
+  }
+  HostCsr X;
+  X.nrows = X.ncols = n;
+  X.rp.resize(n + 1);
+  X.col.resize((size_t)n * n);
+  X.val.assign((size_t)n * n, 0.0);
+  for (int64_t i = 0; i <= n; ++i) X.rp[i] = i * n;
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < n; ++j) X.col[i * n + j] = (int32_t)j;
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<double> y(n), x(n);
+        for (int64_t c = n * t / T; c < n * (t + 1) / T; ++c) {
+          std::fill(y.begin(), y.end(), 0.0);
+          for (int64_t i = c; i < n; ++i) {
+            double sacc = i == c ? 1.0 : 0.0;
+            for (int64_t k = c; k < i; ++k) sacc = std::fma(-D[i * n + k], y[k], sacc);
+            y[i] = sacc / D[i * n + i];
+          }
+          for (int64_t i = n - 1; i >= 0; --i) {
+            double sacc = y[i];
+            for (int64_t k = i + 1; k < n; ++k) sacc = std::fma(-D[k * n + i], x[k], sacc);
+            x[i] = sacc / D[i * n + i];
+          }
+          for (int64_t i = 0; i < n; ++i) X.val[i * n + c] = x[i];
+        }
+      });
+    for (auto &x : th) x.join();
+  }
+  RC(upload_level(ctx, ctx->ml_inv, X));
+  return ALFD_OK;
+}
 
 // Aggregate ids over the LOCAL index space [owned | halo] of a matrix' column space:
 // the owned part is given, the halo part is fetched from the owners through the
@@ -3321,8 +3641,16 @@ static int ml_setup(alfd_ctx *ctx) {
   if (c.ml_smooth_degree < 1 || c.ml_coarse_degree < 1 || !(c.ml_smooth_ratio > 1.0) || !(c.ml_coarse_ratio > 1.0))
     return ctx->err = "bad multilevel parameters", ALFD_E_INVALID;
   int nlev = 0;
-  while (nlev < ALFD_MAX_LEVELS && !ctx->ml_agg[nlev].empty()) ++nlev;
-  if (nlev == 0) return ctx->err = "alfd_set_aggregates must precede alfd_setup for ALFD_PREC_MULTILEVEL", ALFD_E_NOT_SETUP;
+  bool any_P = false;
+  while (nlev < ALFD_MAX_LEVELS && (!ctx->ml_agg[nlev].empty() || !ctx->ml_P[nlev].rp.empty())) {
+    any_P = any_P || !ctx->ml_P[nlev].rp.empty();
+    ++nlev;
+  }
+  if (nlev == 0)
+    return ctx->err = "alfd_set_aggregates / alfd_set_prolongator must precede alfd_setup for ALFD_PREC_MULTILEVEL", ALFD_E_NOT_SETUP;
+  if (ctx->nranks > 1 && (any_P || c.ml_patch_degree > 0 || c.ml_coarse_direct > 0))
+    return ctx->err = "CSR prolongators, the interface patch and the direct coarsest solve are single-rank for now", ALFD_E_UNSUPPORTED;
+  if (c.ml_patch_degree > 0 && !(c.ml_patch_ratio > 1.0)) return ctx->err = "bad ml_patch_ratio", ALFD_E_INVALID;
   const int rk = ctx->rank, last = ctx->nblocks - 1;
   // rank offsets of every level's unknowns: level 0 = block 0, level l+1 = ml_coff[l]
   std::vector<std::vector<int64_t>> off(nlev + 1);
@@ -3338,9 +3666,11 @@ static int ml_setup(alfd_ctx *ctx) {
     off[0] = {0, ctx->n[0]};
     for (int l = 0; l < nlev; ++l) off[l + 1] = {0, ctx->ml_ncoarse[l]};
   }
-  for (int l = 0; l < nlev; ++l)
-    if ((int64_t)ctx->ml_agg[l].size() != off[l][rk + 1] - off[l][rk])
-      return ctx->err = "aggregates of level " + std::to_string(l) + " do not match this rank's unknowns", ALFD_E_INVALID;
+  for (int l = 0; l < nlev; ++l) {
+    const bool isP = !ctx->ml_P[l].rp.empty();
+    if ((isP ? ctx->ml_P[l].nrows : (int64_t)ctx->ml_agg[l].size()) != off[l][rk + 1] - off[l][rk])
+      return ctx->err = "aggregates / prolongator of level " + std::to_string(l) + " do not match this rank's unknowns", ALFD_E_INVALID;
+  }
   free_levels(ctx);
   ctx->ml.assign(nlev + 1, MlLevel());
   // multi-rank: levels with few unknowns are replicated on every rank after the partitioned build
@@ -3362,6 +3692,7 @@ static int ml_setup(alfd_ctx *ctx) {
   RC(download_csr(ctx, ctx->mat[ALFD_CT], Ct));
   const int64_t lam0 = ctx->nranks > 1 ? ctx->part[last][rk] : 0;
   const int64_t lam_global = ctx->nranks > 1 ? ctx->part[last].back() : ctx->n[last];
+  if (c.ml_patch_degree > 0) RC(patch_setup(ctx, A, C, Ct));
   for (int l = 0; l <= nlev; ++l) {
     MlLevel &L = ctx->ml[l];
     const int64_t n = off[l][rk + 1] - off[l][rk];
@@ -3402,6 +3733,29 @@ static int ml_setup(alfd_ctx *ctx) {
       HIPC(hipMemsetAsync(L.r, 0, L.npad * sizeof(double), ctx->stream));
     }
     if (l == nlev) break;
+    if (!ctx->ml_P[l].rp.empty()) {
+      // ---- next level through a general CSR prolongator (single rank): A_c = P^T (A P), C_c = C P, Ct_c = C_c^T
+      const HostCsr &Pm = ctx->ml_P[l];
+      HostCsr AP;
+      transpose_host(Pm, R);
+      spgemm_host(A, Pm, AP);
+      spgemm_host(R, AP, An);
+      AP = HostCsr();
+      spgemm_host(C, Pm, Cn);
+      transpose_host(Cn, Ctn);
+      MlLevel &Nx = ctx->ml[l + 1];
+      RC(upload_level_part(ctx, Nx.A, An, nullptr, false));
+      RC(upload_level_part(ctx, Nx.C, Cn, nullptr, false));
+      RC(upload_level_part(ctx, Nx.Ct, Ctn, nullptr, false));
+      RC(upload_level_part(ctx, Nx.P, Pm, nullptr, true));
+      RC(upload_level_part(ctx, Nx.R, R, nullptr, true));
+      if (l + 1 < nlev) {
+        A = std::move(An);
+        C = std::move(Cn);
+        Ct = std::move(Ctn);
+      }
+      continue;
+    }
     // ---- next level: Galerkin products of this rank's rows
     const std::vector<int32_t> &aggG = ctx->ml_agg[l];  // owned fine dof -> GLOBAL coarse id (or -1)
     const double *w = ctx->ml_wgt[l].empty() ? nullptr : ctx->ml_wgt[l].data();
@@ -3459,6 +3813,13 @@ static int ml_setup(alfd_ctx *ctx) {
       RC(download_csr(ctx, Nx.C, C));
       RC(download_csr(ctx, Nx.Ct, Ct));
     }
+  }
+  if (c.ml_coarse_direct > 0 && ctx->ml[nlev].n > 0 && ctx->ml[nlev].n <= c.ml_coarse_direct) {
+    // An / Cn / Ctn still hold the coarsest level (global = local column ids on one rank)
+    std::vector<double> w(ctx->n[last]);
+    HIPC(hipMemcpyAsync(w.data(), ctx->diag[ALFD_INVW], w.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    RC(coarse_inverse(ctx, An, Cn, Ctn, w));
   }
   if (rep_from > 0) {
     // ---- replicate levels rep_from .. nlev: gather operators, diagonals and W on every rank
@@ -4030,6 +4391,9 @@ void alfd_default_config(alfd_config *c, int variant) {
   c->ml_coarse_ratio = 400.0;
   c->w_inverse = ALFD_W_DIAGONAL;
   c->mass = {ALFD_CTRL_REDUCTION, 1000, 1e-30, 1e-14};
+  c->ml_patch_degree = 0;
+  c->ml_coarse_direct = 0;
+  c->ml_patch_ratio = 30.0;
 }
 
 int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t *agg, const double *weight,
@@ -4044,7 +4408,39 @@ int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t
   else
     ctx->ml_wgt[level].clear();
   ctx->ml_ncoarse[level] = n_coarse;
-  for (int l = level + 1; l < ALFD_MAX_LEVELS; ++l) ctx->ml_agg[l].clear(), ctx->ml_wgt[l].clear();
+  ctx->ml_P[level] = HostCsr();
+  for (int l = level + 1; l < ALFD_MAX_LEVELS; ++l) ctx->ml_agg[l].clear(), ctx->ml_wgt[l].clear(), ctx->ml_P[l] = HostCsr();
+  ctx->is_setup = false;
+  return ALFD_OK;
+}
+
+int alfd_set_prolongator(alfd_ctx_t ctx, int level, int64_t n_fine, int64_t n_coarse, const int64_t *row_ptr,
+                         const int32_t *col, const double *val) {
+  CHECK_CTX();
+  if (level < 0 || level >= ALFD_MAX_LEVELS || n_fine < 0 || n_coarse <= 0 || n_coarse > INT32_MAX || !row_ptr ||
+      row_ptr[0] != 0)
+    return ctx->err = "alfd_set_prolongator: bad arguments", ALFD_E_INVALID;
+  for (int64_t i = 0; i < n_fine; ++i)
+    if (row_ptr[i + 1] < row_ptr[i]) return ctx->err = "alfd_set_prolongator: row_ptr must be monotone", ALFD_E_INVALID;
+  const int64_t nnz = row_ptr[n_fine];
+  if (nnz > 0 && (!col || !val)) return ctx->err = "alfd_set_prolongator: col / val missing", ALFD_E_INVALID;
+  for (int64_t i = 0; i < n_fine; ++i)
+    for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k)
+      if (col[k] < 0 || col[k] >= n_coarse || (k > row_ptr[i] && col[k] <= col[k - 1]))
+        return ctx->err = "alfd_set_prolongator: columns must be ascending and inside [0, n_coarse)", ALFD_E_INVALID;
+  HostCsr &P = ctx->ml_P[level];
+  P.nrows = n_fine;
+  P.ncols = n_coarse;
+  P.rp.assign(row_ptr, row_ptr + n_fine + 1);
+  P.col.assign(col, col + nnz);
+  P.val.assign(val, val + nnz);
+  ctx->ml_agg[level].clear();
+  ctx->ml_wgt[level].clear();
+  ctx->ml_ncoarse[level] = n_coarse;
+  for (int l = level + 1; l < ALFD_MAX_LEVELS; ++l) {   // levels below are redefined by later calls
+    ctx->ml_agg[l].clear();
+    ctx->ml_P[l] = HostCsr();
+  }
   ctx->is_setup = false;
   return ALFD_OK;
 }
@@ -4059,7 +4455,7 @@ int alfd_build_aggregates(alfd_ctx_t ctx, int32_t block_size, double threshold, 
   if (max_levels < 1 || max_levels > ALFD_MAX_LEVELS - 1) max_levels = ALFD_MAX_LEVELS - 1;
   HostCsr A, An;
   RC(download_csr(ctx, ctx->mat[ALFD_A], A));
-  for (int l = 0; l < ALFD_MAX_LEVELS; ++l) ctx->ml_agg[l].clear(), ctx->ml_wgt[l].clear();
+  for (int l = 0; l < ALFD_MAX_LEVELS; ++l) ctx->ml_agg[l].clear(), ctx->ml_wgt[l].clear(), ctx->ml_P[l] = HostCsr();
   int nlev = 0;
   while (nlev < max_levels) {
     std::vector<int32_t> agg;

@@ -1413,4 +1413,11 @@ __global__ void gather_kernel(int64_t n, const int32_t *__restrict__ idx, const 
   if (i < n) out[i] = x[idx[i]];
 }
 
+// out[idx[i]] += x[i]   (interface-patch corrections: idx lists distinct rows)
+__global__ void scatter_add_kernel(int64_t n, const int32_t *__restrict__ idx, const double *__restrict__ x,
+                                   double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[idx[i]] = out[idx[i]] + x[i];
+}
+
 }  // namespace alfd

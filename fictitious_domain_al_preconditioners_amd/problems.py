@@ -431,3 +431,57 @@ def geometric_aggregates(pb: SyntheticProblem, a: int = 2, min_coarse: int = 600
         cur = nxt
         first = False
     return levels
+
+
+def _interp1d(n_fine_cells: int, n_coarse_cells: int):
+    """Linear interpolation between two uniform grids of one interval: fine node i (of n_fine_cells + 1)
+    from the coarse nodes either side of it.  Returns (rows, cols, vals) with exact weights 1 and 1/2 on
+    nested grids."""
+    rows, cols, vals = [], [], []
+    for i in range(n_fine_cells + 1):
+        num = i * n_coarse_cells                  # position i / n_fine_cells in coarse cells = num / n_fine_cells
+        j, rem = divmod(num, n_fine_cells)
+        if rem == 0:
+            rows.append(i); cols.append(j); vals.append(1.0)
+        else:
+            fr = rem / n_fine_cells
+            rows += [i, i]; cols += [j, j + 1]; vals += [1.0 - fr, fr]
+    return np.asarray(rows), np.asarray(cols), np.asarray(vals)
+
+
+def tensor_prolongators(params: dict, min_coarse: int = 400, max_levels: int = 7):
+    """Geometric multigrid transfers of the tensor-grid background space, as CSR prolongators for
+    Context.set_prolongator (alfd_set_prolongator): level 0 embeds the Q1 space of the SAME mesh into the
+    nodal grid of the degree-p space (for Q2 that is linear interpolation from n to 2n cells -- the Q1
+    functions are members of the Q2 space), every further level interpolates (bi/tri)linearly from a grid
+    of ceil(n/2) cells (nested when n is even).  All components of a node interpolate alike; Dirichlet
+    (boundary) nodes are neither interpolated to nor from, coarse unknowns are the INTERIOR nodes of the
+    coarse grid in lexicographic order, node-major.  What a deal.II caller takes from MGTransferPrebuilt /
+    FETools::get_interpolation_matrix.  Returns [(Csr P, n_coarse), ...]."""
+    import scipy.sparse as sp
+    dim, ncomp, degree = params["dim"], params["ncomp"], params["degree"]
+    nf = degree * params["n_cells"]               # cells of the fine nodal grid
+    nc = params["n_cells"] if degree > 1 else (params["n_cells"] + 1) // 2
+    fine_is_full = True                           # level 0 rows = all nodes (boundary rows stay empty)
+    levels = []
+    while len(levels) < max_levels and nc >= 2:
+        r, c, v = _interp1d(nf, nc)
+        p1 = sp.csr_matrix((v, (r, c)), shape=(nf + 1, nc + 1))
+        if fine_is_full:                          # zero the rows of boundary nodes, keep the row count
+            keep = np.ones(nf + 1); keep[0] = keep[-1] = 0.0
+            p1f = sp.diags(keep) @ p1
+        else:
+            p1f = p1[1:-1, :]                     # interior-only numbering on this level
+        p1c = p1f[:, 1:-1]                        # coarse interior nodes only
+        pd = p1c
+        for _ in range(dim - 1):
+            pd = sp.kron(p1c, pd)                 # axis 0 fastest: kron(P_z, kron(P_y, P_x))
+        pv = sp.kron(pd, sp.identity(ncomp)).tocsr() if ncomp > 1 else pd.tocsr()
+        pv.eliminate_zeros()
+        pv.sort_indices()
+        n_coarse = int(pv.shape[1])
+        levels.append((Csr.from_scipy(pv), n_coarse))
+        if n_coarse <= min_coarse:
+            break
+        nf, nc, fine_is_full = nc, (nc + 1) // 2, False
+    return levels

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "alfd_host_window_plan", "alfd_set_tunable", "alfd_build_aggregates", "alfd_get_aggregates",
     "alfd_host_aggregate_level", "alfd_comm_init_host",
     "alfd_get_device_memory", "alfd_set_row_blocks", "alfd_host_stream_plan",
-    "alfd_host_row_blocks_from_points", "alfd_host_stream_plan_short",
+    "alfd_host_row_blocks_from_points", "alfd_host_stream_plan_short", "alfd_set_prolongator",
 ]
 
 
@@ -94,6 +94,7 @@ def load_library():
         "alfd_comm_init_local": (C.c_int, [vp, vp, C.c_int]),
         "alfd_set_aggregates": (C.c_int, [vp, C.c_int, i64, vp, vp, i64]),
         "alfd_set_aggregate_partition": (C.c_int, [vp, C.c_int, vp]),
+        "alfd_set_prolongator": (C.c_int, [vp, C.c_int, i64, i64, vp, vp, vp]),
         "alfd_get_matrix_info": (C.c_int, [vp, C.c_int, C.POINTER(_abi.MatrixInfo)]),
         "alfd_bench_spmv_format": (C.c_int, [vp, C.c_int, i32, C.c_int, C.POINTER(dbl), C.POINTER(dbl)]),
         "alfd_host_window_plan": (C.c_int, [i64, vp, vp, vp, i32, i32, C.POINTER(_abi.WindowPlanInfo)]),
@@ -196,6 +197,11 @@ class Context:
         w = None if weight is None else np.ascontiguousarray(weight, np.float64)
         self._ck(self._lib.alfd_set_aggregates(self._h, level, agg.size, agg.ctypes.data,
                                                None if w is None else w.ctypes.data, int(n_coarse)))
+
+    def set_prolongator(self, level, P):
+        """CSR prolongator (problems.Csr, n_fine x n_coarse) of a multigrid level: alfd_set_prolongator."""
+        self._ck(self._lib.alfd_set_prolongator(self._h, level, P.nrows, P.ncols, P.row_ptr.ctypes.data,
+                                                P.col.ctypes.data, P.val.ctypes.data))
 
     def build_aggregates(self, block_size=1, threshold=0.02, max_aggregate_nodes=8, min_coarse=600, max_levels=7):
         """Algebraic aggregation from the uploaded A alone (alfd_build_aggregates); returns
@@ -469,12 +475,16 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_bloc
     """Upload a problems.SyntheticProblem (whole, or this rank's rows) with the
     reference's diagonal choices: W^-1 = 1/M_ii^2 (stokes...:976-978), lumped
     pressure mass (stokes...:946-954).  aggregates: [(agg, n_coarse), ...] for
-    ALFD_PREC_MULTILEVEL (problems.geometric_aggregates).  row_blocks: (block_ptr, rows)
+    ALFD_PREC_MULTILEVEL (problems.geometric_aggregates), or [(Csr P, n_coarse), ...]
+    (problems.tensor_prolongators).  row_blocks: (block_ptr, rows)
     for the SpMV on A (Context.set_row_blocks, e.g. problems.brick_row_blocks)."""
     if row_blocks is not None:
         ctx.set_row_blocks(_abi.A, *row_blocks)
     for level, entry in enumerate(aggregates or []):
         agg, nc = entry[0], entry[1]
+        if hasattr(agg, "row_ptr"):                       # a CSR prolongator (problems.tensor_prolongators)
+            ctx.set_prolongator(level, agg)
+            continue
         ctx.set_aggregates(level, agg, nc)
         if len(entry) > 2 and entry[2] is not None:      # (agg_local, n_coarse_global, coarse_offsets)
             ctx.set_aggregate_partition(level, entry[2])

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 10
+#define ALFD_ABI_VERSION 11
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -191,7 +191,20 @@ typedef struct alfd_config {
   int32_t w_inverse;          /* enum alfd_w_inverse */
   alfd_control mass;          /* CG on M for the exact W^-1: ReductionControl(1000, 1e-30, 1e-14) */
   int32_t fgmres_flavour;     /* enum alfd_fgmres_flavour */
-  int32_t reserved0;
+  int32_t ml_smooth_degree_coarse; /* > 0: smoother degree on levels >= 1 (ml_smooth_degree then applies to level 0
+                                      only: the fine operator is the expensive one, the coarse ones are nearly free) */
+  /* ALFD_PREC_MULTILEVEL, round 3 (ML in the reference: smoothed prolongators, 2 smoother sweeps, KLU on
+   * the coarsest level -- utilities.h:304-317):
+   * ml_patch_degree > 0 wraps the V-cycle symmetrically into two corrections on the INTERFACE PATCH, the
+   * rows S of the (1,1) block the coupling matrix touches (non-empty rows of Ct): z1 = E q(Aug_SS) E^T r,
+   * z2 = z1 + V(r - Aug z1), z = z2 + E q(Aug_SS) E^T (r - Aug z2), q = Chebyshev polynomial of that degree
+   * in D^-1 Aug_SS over [lambda_max / ml_patch_ratio, lambda_max].  The penalty gamma Ct W^-1 C is what a
+   * multigrid cycle on the background mesh cannot resolve; it lives on S only (a few 10^4 rows at 10^7 DoF).
+   * ml_coarse_direct > 0: when the coarsest level has at most that many unknowns its operator is inverted
+   * explicitly (dense Cholesky at setup, one dense product per cycle) instead of the Chebyshev sweep. */
+  int32_t ml_patch_degree;
+  int32_t ml_coarse_direct;
+  double ml_patch_ratio;
 } alfd_config;
 
 typedef struct alfd_result {
@@ -288,6 +301,16 @@ int alfd_set_diag(alfd_ctx_t ctx, int slot, int64_t n, const double *d);
  * P^T (A + gamma Ct invW C) P, kept factored as (P^T A P) + gamma (C P)^T invW (C P). */
 int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t *agg, const double *weight,
                         int64_t n_coarse);
+/* General prolongator of level l as a CSR matrix P (n_fine x n_coarse, columns ascending per row):
+ * geometric multigrid transfers (e.g. the embedding of Q1 into Q2 on the same mesh followed by trilinear
+ * interpolation between nested or non-nested grids -- what deal.II's MGTransfer / FETools interpolation
+ * matrices hold), or a smoothed-aggregation prolongator as ML builds it (utilities.h:304-317).  Replaces
+ * the aggregates of that level; rows without entries (Dirichlet / constrained unknowns) are not
+ * represented on the coarse level.  Coarse operators are the Galerkin products, formed in two steps,
+ * (A P) then P^T (A P), each output entry a sequential fma chain in CSR order.
+ * Single rank for now: ALFD_E_UNSUPPORTED at alfd_setup on a partitioned context. */
+int alfd_set_prolongator(alfd_ctx_t ctx, int level, int64_t n_fine, int64_t n_coarse, const int64_t *row_ptr,
+                         const int32_t *col, const double *val);
 /* Multi-rank: agg[] holds this rank's unknowns of level l and GLOBAL coarse ids; the coarse
  * unknowns of each level are numbered rank-major, coarse_offsets[nranks+1] gives the rank
  * ranges.  An aggregate must not span two ranks. */

@@ -232,6 +232,7 @@ struct Problem {
   const double *ml_wgt[ALFD_MAX_LEVELS] = {};
   int64_t ml_nc[ALFD_MAX_LEVELS] = {};
   const int64_t *ml_off[ALFD_MAX_LEVELS] = {};        // emulated ranks: offsets of level l+1's unknowns
+  Csr ml_P[ALFD_MAX_LEVELS];                          // CSR prolongator of a level (replaces its aggregates)
   struct Level {
     Csr A, C, Ct, Pm, R;
     int64_t n = 0;
@@ -239,6 +240,15 @@ struct Problem {
     double lmax = 0;
   };
   std::vector<Level> ml;
+  Csr ml_inv;                                         // explicit inverse of the coarsest operator (ml_coarse_direct)
+  // interface patch (alfd_config::ml_patch_degree > 0): S = non-empty rows of Ct
+  struct Patch {
+    bool on = false;
+    std::vector<int32_t> S, T;                        // patch rows; rows of A with a column in S
+    Csr Ass, As, Ats, Cs, Cts;                        // A[S,S], A[S,:], A[T,S] (compact rows), C[:,S], Ct[S,:]
+    std::vector<double> dinv;
+    double lmax = 0;
+  } patch;
   std::vector<std::vector<double>> shifted_dinv;
   int64_t rational_its = 0, mass_its = 0;
   int winv_status = 0;  // first failure of a nested mass solve (ALFD_OK otherwise)
@@ -730,27 +740,282 @@ static void level_cheb(Problem &P, int l, int degree, double ratio, const double
   }
 }
 
-static void ml_cycle(Problem &P, int l, const double *r, double *z) {
+// ---- general CSR prolongators: two-step Galerkin products -------------------------
+// out = A * Pm.  Every output entry (i, J) is ONE sequential fma chain: entries k of row i of A in
+// CSR order, entries of row col_k of Pm in CSR order, acc_J = fma(a_ik, p_kJ, acc_J) from 0.
+// The finished row is sorted by column.
+static void spgemm(const Csr &A, const Csr &Pm, Csr &out) {
+  out.nrows = A.nrows;
+  out.ncols = Pm.ncols;
+  std::vector<std::vector<std::pair<int32_t, double>>> rows(A.nrows);
+#pragma omp parallel
+  {
+    std::vector<int64_t> marker(Pm.ncols, -1);
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = 0; i < A.nrows; ++i) {
+      std::vector<std::pair<int32_t, double>> &row = rows[i];
+      for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+        const double a = A.val[k];
+        const int64_t j = A.col[k];
+        for (int64_t e = Pm.rp[j]; e < Pm.rp[j + 1]; ++e) {
+          const int32_t J = Pm.col[e];
+          if (marker[J] < 0) {
+            marker[J] = (int64_t)row.size();
+            row.emplace_back(J, std::fma(a, Pm.val[e], 0.0));
+          } else {
+            row[marker[J]].second = std::fma(a, Pm.val[e], row[marker[J]].second);
+          }
+        }
+      }
+      for (auto &e : row) marker[e.first] = -1;
+      std::sort(row.begin(), row.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+    }
+  }
+  out.own_rp.assign(A.nrows + 1, 0);
+  for (int64_t i = 0; i < A.nrows; ++i) out.own_rp[i + 1] = out.own_rp[i] + (int64_t)rows[i].size();
+  out.own_col.resize(out.own_rp[A.nrows]);
+  out.own_val.resize(out.own_rp[A.nrows]);
+  for (int64_t i = 0; i < A.nrows; ++i) {
+    int64_t p = out.own_rp[i];
+    for (auto &e : rows[i]) {
+      out.own_col[p] = e.first;
+      out.own_val[p++] = e.second;
+    }
+  }
+  out.rp = out.own_rp.data();
+  out.col = out.own_col.data();
+  out.val = out.own_val.data();
+}
+
+// rows `rows` of A (compact row numbering), columns kept if colmap[col] >= 0 (renumbered), or all
+// columns when colmap == nullptr; CSR order preserved
+static void extract(const Csr &A, const std::vector<int32_t> &rows, const int32_t *colmap, int64_t ncols, Csr &out) {
+  out.nrows = (int64_t)rows.size();
+  out.ncols = ncols;
+  out.own_rp.assign(rows.size() + 1, 0);
+  out.own_col.clear();
+  out.own_val.clear();
+  for (size_t q = 0; q < rows.size(); ++q) {
+    const int64_t i = rows[q];
+    for (int64_t k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+      const int32_t c = colmap ? colmap[A.col[k]] : A.col[k];
+      if (c < 0) continue;
+      out.own_col.push_back(c);
+      out.own_val.push_back(A.val[k]);
+    }
+    out.own_rp[q + 1] = (int64_t)out.own_col.size();
+  }
+  out.rp = out.own_rp.data();
+  out.col = out.own_col.data();
+  out.val = out.own_val.data();
+  choose_lanes(out);
+}
+
+// y = Aug_SS x on patch-compact vectors
+static void patch_op(Problem &P, const double *x, double *y, std::vector<double> &t) {
+  const Problem::Patch &Q = P.patch;
+  spmv(Q.Ass, x, y, 0, 0.0);
+  if (P.cfg.aug_assembled) return;
+  t.resize(Q.Cs.nrows);
+  spmv(Q.Cs, x, t.data(), 0, 0.0);
+  pmul(Q.Cs.nrows, P.diag[ALFD_INVW], t.data(), t.data());
+  spmv(Q.Cts, t.data(), y, 1, P.cfg.gamma);
+}
+
+// z = q(D^-1 Aug_SS) D^-1 r: Chebyshev of degree ml_patch_degree over [lmax / ml_patch_ratio, lmax]
+static void patch_cheb(Problem &P, const double *r, double *z) {
+  const Problem::Patch &Q = P.patch;
+  const int64_t n = (int64_t)Q.S.size();
+  const double *dinv = Q.dinv.data();
+  const double lmax = Q.lmax, lmin = lmax / P.cfg.ml_patch_ratio;
+  const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  const int degree = P.cfg.ml_patch_degree;
+  std::vector<double> d(n), res, tmp(n), t;
+  const double inv_theta = 1.0 / theta;
+  for (int64_t i = 0; i < n; ++i) {
+    d[i] = inv_theta * (dinv[i] * r[i]);
+    z[i] = d[i];
+  }
+  if (degree > 1) res.assign(r, r + n);
+  for (int j = 1; j < degree; ++j) {
+    patch_op(P, d.data(), tmp.data(), t);
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    const double c1 = rho_new * rho, c2 = 2.0 * rho_new / delta;
+    for (int64_t i = 0; i < n; ++i) {
+      res[i] = res[i] - tmp[i];
+      d[i] = std::fma(c1, d[i], c2 * (dinv[i] * res[i]));
+      z[i] = z[i] + d[i];
+    }
+    rho = rho_new;
+  }
+}
+
+static void ml_vcycle(Problem &P, int l, const double *r, double *z) {
   const alfd_config &c = P.cfg;
   const int last = (int)P.ml.size() - 1;
-  if (l == last) return level_cheb(P, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  if (l == last) {
+    if (P.ml_inv.present()) return spmv(P.ml_inv, r, z, 0, 0.0);
+    return level_cheb(P, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  }
   const int64_t n = P.ml[l].n, nc = P.ml[l + 1].n;
   std::vector<double> t(n), rc(nc), ec(nc), e(n), tl;
-  level_cheb(P, l, c.ml_smooth_degree, c.ml_smooth_ratio, r, z);
+  const int sdeg = l > 0 && c.ml_smooth_degree_coarse > 0 ? c.ml_smooth_degree_coarse : c.ml_smooth_degree;
+  level_cheb(P, l, sdeg, c.ml_smooth_ratio, r, z);
   level_op(P, l, z, t.data(), tl);
   sub_from(n, r, t.data());
   spmv(P.ml[l + 1].R, t.data(), rc.data(), 0, 0.0);
-  ml_cycle(P, l + 1, rc.data(), ec.data());
+  ml_vcycle(P, l + 1, rc.data(), ec.data());
   spmv(P.ml[l + 1].Pm, ec.data(), z, 1, 1.0);
   level_op(P, l, z, t.data(), tl);
   sub_from(n, r, t.data());
-  level_cheb(P, l, c.ml_smooth_degree, c.ml_smooth_ratio, t.data(), e.data());
+  level_cheb(P, l, sdeg, c.ml_smooth_ratio, t.data(), e.data());
   for (int64_t i = 0; i < n; ++i) z[i] = std::fma(1.0, e[i], z[i]);
+}
+
+// The inner preconditioner: the V-cycle, wrapped (ml_patch_degree > 0) into the two interface-patch
+// corrections  z1 = E q E^T r;  z2 = z1 + V(r - Aug z1);  z = z2 + E q E^T (r - Aug z2).
+static void ml_cycle(Problem &P, int l, const double *r, double *z) {
+  const Problem::Patch &Q = P.patch;
+  if (l != 0 || !Q.on) return ml_vcycle(P, l, r, z);
+  const int64_t n = P.ml[0].n, m = (int64_t)Q.S.size();
+  const bool pen = !P.cfg.aug_assembled;
+  std::vector<double> rS(m), zS(m), uS(m), eS(m), rr(r, r + n), tl(Q.Cs.nrows);
+  for (int64_t q = 0; q < m; ++q) rS[q] = r[Q.S[q]];
+  patch_cheb(P, rS.data(), zS.data());
+  // rr = r - Aug E zS: rows T of A, the penalty through C[:,S] and the full Ct
+  {
+    std::vector<double> y((size_t)Q.Ats.nrows);
+    spmv(Q.Ats, zS.data(), y.data(), 0, 0.0);
+    for (int64_t q = 0; q < Q.Ats.nrows; ++q) rr[Q.T[q]] = std::fma(-1.0, y[q], rr[Q.T[q]]);
+    if (pen) {
+      spmv(Q.Cs, zS.data(), tl.data(), 0, 0.0);
+      pmul(Q.Cs.nrows, P.diag[ALFD_INVW], tl.data(), tl.data());
+      spmv(P.mat[ALFD_CT], tl.data(), rr.data(), 1, -P.cfg.gamma);
+    }
+  }
+  ml_vcycle(P, 0, rr.data(), z);
+  for (int64_t q = 0; q < m; ++q) z[Q.S[q]] = z[Q.S[q]] + zS[q];
+  // (r - Aug z) on S
+  spmv(Q.As, z, uS.data(), 0, 0.0);
+  if (pen) {
+    spmv(P.mat[ALFD_C], z, tl.data(), 0, 0.0);
+    pmul(Q.Cs.nrows, P.diag[ALFD_INVW], tl.data(), tl.data());
+    spmv(Q.Cts, tl.data(), uS.data(), 1, P.cfg.gamma);
+  }
+  sub_from(m, rS.data(), uS.data());
+  patch_cheb(P, uS.data(), eS.data());
+  for (int64_t q = 0; q < m; ++q) z[Q.S[q]] = z[Q.S[q]] + eS[q];
+}
+
+static void patch_setup(Problem &P) {
+  Problem::Patch &Q = P.patch;
+  const Csr &A = P.mat[ALFD_A], &C = P.mat[ALFD_C], &Ct = P.mat[ALFD_CT];
+  const int64_t n = P.n[0];
+  Q.S.clear();
+  Q.T.clear();
+  std::vector<int32_t> pos(n, -1);
+  for (int64_t i = 0; i < n; ++i)
+    if (Ct.rp[i + 1] > Ct.rp[i]) {
+      pos[i] = (int32_t)Q.S.size();
+      Q.S.push_back((int32_t)i);
+    }
+  const int64_t m = (int64_t)Q.S.size();
+  Q.on = m > 0;
+  if (!Q.on) return;
+  for (int64_t i = 0; i < n; ++i) {
+    bool hit = false;
+    for (int64_t k = A.rp[i]; k < A.rp[i + 1] && !hit; ++k) hit = pos[A.col[k]] >= 0;
+    if (hit) Q.T.push_back((int32_t)i);
+  }
+  std::vector<int32_t> lam_rows(C.nrows);
+  for (int64_t k = 0; k < C.nrows; ++k) lam_rows[k] = (int32_t)k;
+  extract(A, Q.S, pos.data(), m, Q.Ass);
+  extract(A, Q.S, nullptr, n, Q.As);
+  extract(A, Q.T, pos.data(), m, Q.Ats);
+  extract(C, lam_rows, pos.data(), m, Q.Cs);
+  extract(Ct, Q.S, nullptr, Ct.ncols, Q.Cts);
+  Q.dinv.resize(m);
+  for (int64_t q = 0; q < m; ++q) Q.dinv[q] = P.dinv_aug[Q.S[q]];
+  std::vector<double> v(m), wv(m), t;
+  for (int64_t i = 0; i < m; ++i) v[i] = 1.0 + (double)(((uint64_t)i * 2654435761ull) & 1023ull) * (1.0 / 1024.0);
+  double lam = 0.0;
+  for (int it = 0; it < P.cfg.cheb_power_its; ++it) {
+    const double nv = std::sqrt(dot(m, v.data(), v.data()));
+    scale(m, 1.0 / nv, v.data());
+    patch_op(P, v.data(), wv.data(), t);
+    pmul(m, Q.dinv.data(), wv.data(), wv.data());
+    lam = std::sqrt(dot(m, wv.data(), wv.data()));
+    v.swap(wv);
+  }
+  Q.lmax = lam * P.cfg.cheb_safety;
+}
+
+// Explicit inverse of the coarsest Aug (dense Cholesky, row-oriented, sequential fma chains); false when
+// the matrix is not positive definite.  Stored as a dense CSR so that the product runs in canonical SpMV order.
+static bool coarse_inverse(Problem &P) {
+  const Problem::Level &L = P.ml.back();
+  const int64_t n = L.n;
+  std::vector<double> D((size_t)n * n, 0.0);
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t k = L.A.rp[i]; k < L.A.rp[i + 1]; ++k) D[i * n + L.A.col[k]] = L.A.val[k];
+  if (!P.cfg.aug_assembled)
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t k = L.Ct.rp[i]; k < L.Ct.rp[i + 1]; ++k) {
+        const int64_t lam = L.Ct.col[k];
+        const double s = (P.cfg.gamma * P.diag[ALFD_INVW][lam]) * L.Ct.val[k];
+        for (int64_t e = L.C.rp[lam]; e < L.C.rp[lam + 1]; ++e)
+          D[i * n + L.C.col[e]] = std::fma(s, L.C.val[e], D[i * n + L.C.col[e]]);
+      }
+  for (int64_t j = 0; j < n; ++j) {
+    double d = D[j * n + j];
+    for (int64_t k = 0; k < j; ++k) d = std::fma(-D[j * n + k], D[j * n + k], d);
+    if (!(d > 0.0)) return false;
+    const double ljj = std::sqrt(d);
+    D[j * n + j] = ljj;
+#pragma omp parallel for schedule(static) if (n - j > 256)
+    for (int64_t i = j + 1; i < n; ++i) {
+      double sacc = D[i * n + j];
+      for (int64_t k = 0; k < j; ++k) sacc = std::fma(-D[i * n + k], D[j * n + k], sacc);
+      D[i * n + j] = sacc / ljj;
+    }
+  }
+  Csr &X = P.ml_inv;
+  X.nrows = X.ncols = n;
+  X.own_rp.resize(n + 1);
+  X.own_col.resize((size_t)n * n);
+  X.own_val.assign((size_t)n * n, 0.0);
+  for (int64_t i = 0; i <= n; ++i) X.own_rp[i] = i * n;
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < n; ++j) X.own_col[i * n + j] = (int32_t)j;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t c = 0; c < n; ++c) {
+    std::vector<double> y(n, 0.0), x(n, 0.0);
+    for (int64_t i = c; i < n; ++i) {
+      double sacc = i == c ? 1.0 : 0.0;
+      for (int64_t k = c; k < i; ++k) sacc = std::fma(-D[i * n + k], y[k], sacc);
+      y[i] = sacc / D[i * n + i];
+    }
+    for (int64_t i = n - 1; i >= 0; --i) {
+      double sacc = y[i];
+      for (int64_t k = i + 1; k < n; ++k) sacc = std::fma(-D[k * n + i], x[k], sacc);
+      x[i] = sacc / D[i * n + i];
+    }
+    for (int64_t i = 0; i < n; ++i) X.own_val[i * n + c] = x[i];
+  }
+  X.rp = X.own_rp.data();
+  X.col = X.own_col.data();
+  X.val = X.own_val.data();
+  choose_lanes(X);
+  return true;
 }
 
 static void ml_setup(Problem &P) {
   const int nlev = P.ml_nlev;
   P.ml.assign(nlev + 1, Problem::Level());
+  P.ml_inv = Csr();
+  P.patch = Problem::Patch();
   P.ml[0].n = P.n[0];
   P.ml[0].lmax = P.lam_max[OP_AUG];
   for (int l = 0; l < nlev; ++l) {
@@ -758,6 +1023,21 @@ static void ml_setup(Problem &P) {
     const Csr &C = l == 0 ? P.mat[ALFD_C] : P.ml[l].C;
     Problem::Level &N = P.ml[l + 1];
     const int64_t n = P.ml[l].n, nc = P.ml_nc[l];
+    if (P.ml_P[l].present()) {
+      // general prolongator: A_c = P^T (A P), C_c = C P, Ct_c = C_c^T
+      const Csr &Pm = P.ml_P[l];
+      N.Pm.nrows = n;
+      N.Pm.ncols = nc;
+      N.Pm.rp = Pm.rp;
+      N.Pm.col = Pm.col;
+      N.Pm.val = Pm.val;
+      transpose_into(N.Pm, N.R);
+      Csr AP;
+      spgemm(A, N.Pm, AP);
+      spgemm(N.R, AP, N.A);
+      spgemm(C, N.Pm, N.C);
+      transpose_into(N.C, N.Ct);
+    } else {
     const int32_t *agg = P.ml_agg[l];
     const double *w = P.ml_wgt[l];
     galerkin(A, agg, w, nc, agg, w, nc, N.A);
@@ -778,6 +1058,7 @@ static void ml_setup(Problem &P) {
     N.Pm.col = N.Pm.own_col.data();
     N.Pm.val = N.Pm.own_val.data();
     transpose_into(N.Pm, N.R);
+    }
     for (Csr *m : {&N.A, &N.C, &N.Ct, &N.Pm, &N.R}) choose_lanes(*m);
     N.n = nc;
     N.dinv.assign(nc, 0.0);
@@ -807,6 +1088,9 @@ static void ml_setup(Problem &P) {
     }
     N.lmax = lam * P.cfg.cheb_safety;
   }
+  if (P.cfg.ml_coarse_direct > 0 && P.ml.back().n <= P.cfg.ml_coarse_direct && P.ml.back().n > 0 && nlev > 0)
+    if (!coarse_inverse(P)) P.status = ALFD_E_BREAKDOWN;
+  if (P.cfg.ml_patch_degree > 0) patch_setup(P);
 }
 
 // ---- RationalPreconditioner (rational_preconditioner.h:29-63) ----------------
@@ -1352,6 +1636,7 @@ typedef struct orc_problem {
   const double *ml_weight[ALFD_MAX_LEVELS];
   int64_t ml_ncoarse[ALFD_MAX_LEVELS];
   const int64_t *ml_offsets[ALFD_MAX_LEVELS];    // emulated ranks: [nranks+1] offsets of each coarse level
+  orc_csr ml_prolong[ALFD_MAX_LEVELS];           // CSR prolongator of a level (row_ptr != NULL): replaces ml_agg
 } orc_problem;
 
 static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P) {
@@ -1398,7 +1683,18 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
     P.ml_wgt[l] = op->ml_weight[l];
     P.ml_nc[l] = op->ml_ncoarse[l];
     P.ml_off[l] = op->ml_offsets[l];
+    if (op->ml_prolong[l].row_ptr) {
+      orc::Csr &m = P.ml_P[l];
+      m.nrows = op->ml_prolong[l].nrows;
+      m.ncols = op->ml_prolong[l].ncols;
+      m.rp = op->ml_prolong[l].row_ptr;
+      m.col = op->ml_prolong[l].col;
+      m.val = op->ml_prolong[l].val;
+      P.ml_nc[l] = m.ncols;
+      if (op->nranks_emulated > 1) return ALFD_E_UNSUPPORTED;
+    }
   }
+  if (cfg->ml_patch_degree > 0 && op->nranks_emulated > 1) return ALFD_E_UNSUPPORTED;
   if (cfg->inner_prec == ALFD_PREC_MULTILEVEL && P.ml_nlev < 1) return ALFD_E_NOT_SETUP;
   P.pt.nranks = op->nranks_emulated > 1 ? op->nranks_emulated : 1;
   if (P.pt.nranks > 1) {
@@ -1414,7 +1710,7 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
     if (!P.mat[ALFD_M].present() || P.mat[ALFD_M].nrows != P.n[P.nblocks - 1]) return ALFD_E_NOT_SETUP;
   }
   orc::setup(P);
-  return ALFD_OK;
+  return P.status;
 }
 
 static void pack(const orc::Problem &P, const double *const *blocks, std::vector<double> &v) {

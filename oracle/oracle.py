@@ -30,7 +30,7 @@ class _Problem(C.Structure):
                 ("part_offsets", C.c_void_p * _abi.ALFD_MAX_BLOCKS),
                 ("ml_levels", C.c_int32), ("pad_", C.c_int32),
                 ("ml_agg", C.c_void_p * 8), ("ml_weight", C.c_void_p * 8), ("ml_ncoarse", C.c_int64 * 8),
-                ("ml_offsets", C.c_void_p * 8)]
+                ("ml_offsets", C.c_void_p * 8), ("ml_prolong", _Csr * 8)]
 
 
 def build():
@@ -139,6 +139,11 @@ class OracleSystem:
             p.ml_levels = len(aggregates)
             for l, entry in enumerate(aggregates):
                 agg, nc = entry[0], entry[1]
+                if hasattr(agg, "row_ptr"):       # a CSR prolongator (problems.Csr) instead of aggregates
+                    self._keep += (agg,)
+                    p.ml_prolong[l] = _csr_struct(agg)
+                    p.ml_ncoarse[l] = nc
+                    continue
                 agg = np.ascontiguousarray(agg, np.int32)
                 self._keep += (agg,)
                 p.ml_agg[l] = agg.ctypes.data

@@ -146,6 +146,32 @@ def case(name):
             cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
         else:
             cfg.w_inverse = _abi.W_MASS_INV_SQUARED
+    elif name in ("stokes3d_gmg_patch", "stokes3d_gmg", "laplace3d_gmg_patch", "elliptic_modified_gmg_patch"):
+        # round 3: geometric multigrid through CSR prolongators (alfd_set_prolongator: Q2 -> Q1 embedding,
+        # then (bi/tri)linear interpolation), the interface-patch corrections around the V-cycle and the
+        # explicit inverse on the coarsest level -- the counterpart of ML's smoothed prolongators + KLU
+        # (utilities.h:304-317).  "stokes3d_gmg_patch" carries bench.py's settings.
+        if name.startswith("stokes"):
+            pb = problems.stokes3d_sphere(8, 1)
+            cfg = _abi.default_config(_abi.AL_STOKES)
+        elif name.startswith("laplace"):
+            pb = problems.laplace3d_sphere(16, 1)
+            cfg = _abi.default_config(_abi.AL2)
+            cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
+        else:
+            pb = problems.elliptic_interface2d(64, 16)
+            cfg = _abi.default_config(_abi.AL_ELL_MODIFIED)
+            cfg.gamma, cfg.gamma2 = 10.0, 1e-2
+            cfg.inner = _abi.Control(_abi.CTRL_REDUCTION, 100000, 1e-2, 1e-20)
+            cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-10)
+        cfg.inner_prec = _abi.PREC_MULTILEVEL
+        cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 4, 30.0
+        if name == "stokes3d_gmg":              # no patch, Chebyshev sweep on the coarsest level
+            cfg.ml_coarse_degree, cfg.ml_coarse_ratio, cfg.ml_coarse_direct = 12, 100.0, -1
+        else:
+            cfg.ml_patch_degree, cfg.ml_patch_ratio, cfg.ml_coarse_direct = 5, 30.0, 1024
+        cfg.inner.max_steps = 100
+        return pb, cfg
     elif name == "stokes3d_fgmres95":
         # deal.II <= 9.5 SolverFGMRES loop (alfd_fgmres_flavour): MGS, delayed least-squares check; restart 5
         # forces several cycles so that the per-cycle counting rule (m - 1 steps per m applications) shows
@@ -172,6 +198,8 @@ def aggregates_of(pb, cfg):
     """Aggregates handed to both the library and the oracle for ALFD_PREC_MULTILEVEL."""
     if cfg.inner_prec != _abi.PREC_MULTILEVEL:
         return None
+    if cfg.ml_coarse_direct != 0:       # the *_gmg* cases: CSR prolongators of the tensor grid
+        return problems.tensor_prolongators(pb.params, min_coarse=100)
     if cfg.ml_coarse_degree == 10:      # stokes3d_bench_settings: bench.py's --agg-a 2 --min-coarse 4000
         return problems.geometric_aggregates(pb, a=2, min_coarse=4000)
     return problems.geometric_aggregates(pb, a=2, min_coarse=100)
@@ -183,7 +211,8 @@ ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes
              "elliptic_modified_multilevel", "laplace2d_operator_form", "laplace2d_exact_w", "stokes2d_exact_w",
              "laplace2d_operator_form_exact_w", "elliptic_modified_exact_w", "elliptic_ideal_exact_w",
              "elasticity_modified", "elasticity_modified_multilevel", "stokes3d_bench_settings",
-             "stokes3d_fgmres95"]
+             "stokes3d_fgmres95", "stokes3d_gmg_patch", "stokes3d_gmg", "laplace3d_gmg_patch",
+             "elliptic_modified_gmg_patch"]
 
 
 def oracle_system(pb, cfg):

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_version_strerror_and_default_config_mirror():
     lib = solver.load_library()
-    assert lib.alfd_abi_version() == 10
+    assert lib.alfd_abi_version() == 11
     assert b"NoConvergence" in lib.alfd_strerror(_abi.E_NO_CONVERGENCE_INNER)
     assert lib.alfd_strerror(_abi.OK) == b"ok"
     for variant in (_abi.AL2, _abi.AL_STOKES, _abi.AL_ELL_MODIFIED, _abi.RATIONAL):
