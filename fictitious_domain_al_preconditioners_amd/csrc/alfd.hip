@@ -273,6 +273,9 @@ struct alfd_ctx {
   double t_ms[ALFD_T_NCLASSES] = {0, 0, 0, 0};
   int64_t t_launches[ALFD_T_NCLASSES] = {0, 0, 0, 0};
   double t_bytes[ALFD_T_NCLASSES] = {0, 0, 0, 0};
+  double t_fbytes[ALFD_T_NCLASSES] = {0, 0, 0, 0};   // the same launches priced by format bytes
+  double setup_s[ALFD_SETUP_NPHASES] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool upload_since_setup = false;
   std::vector<void *> allocs;
   int spmv_stream_R = 2, spmv_stream_U = 8, spmv_nt = 0, spmv_grid_mult = 8;  // tunables (env ALFD_SPMV_*)
   int spmv_group_R = 4, spmv_group_U = 4;  // batch shape of the short-row window kernel
@@ -446,13 +449,14 @@ struct Timer {
   int cls;
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
-  Timer(alfd_ctx *c, int cl, double bytes) : ctx(c), cls(cl) {
+  Timer(alfd_ctx *c, int cl, double bytes, double fbytes = -1.0) : ctx(c), cls(cl) {
     on = ctx->timing >= 2 || (ctx->timing == 1 && cl == ALFD_T_SPMV_A);
     if (on) {
       hipEventCreate(&a);
       hipEventCreate(&b);
       hipEventRecord(a, ctx->stream);
       ctx->t_bytes[cls] += bytes;
+      ctx->t_fbytes[cls] += fbytes < 0.0 ? bytes : fbytes;
       ctx->t_launches[cls]++;
     }
   }
@@ -461,6 +465,18 @@ struct Timer {
       hipEventRecord(b, ctx->stream);
       ctx->timed.push_back({cls, a, b});
     }
+  }
+};
+
+// accumulates the wall time of a setup phase (device-synchronised at its end)
+struct PhaseClock {
+  alfd_ctx *ctx;
+  int phase;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  PhaseClock(alfd_ctx *c, int ph) : ctx(c), phase(ph) {}
+  ~PhaseClock() {
+    hipStreamSynchronize(ctx->stream);
+    ctx->setup_s[phase] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
 };
 
@@ -719,7 +735,7 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
     if (epi == 3) HIPC(hipMemsetAsync(y2, 0, m.nrows * sizeof(double), ctx->stream));
   }
   if (m.n_list == 0) return ALFD_OK;
-  Timer tm(ctx, cls, m.algorithmic_bytes());
+  Timer tm(ctx, cls, m.algorithmic_bytes(), m.streamed_bytes(!ctx->vi_off, ctx->vs_enable != 0 && !ctx->vi_off));
   if (m.vs.on && ctx->vs_enable && !ctx->vi_off && launch_vs(ctx, m, x, y, epi, alpha, d, y2)) {   // vi_off: alfd_bench_spmv_format(…, 0)
     HIPC(hipGetLastError());
     return ALFD_OK;
@@ -3687,12 +3703,18 @@ static int ml_setup(alfd_ctx *ctx) {
   };
   std::vector<Stash> stash(nlev + 1);
   HostCsr A, C, Ct, An, Cn, Ctn, P, R;
-  RC(download_csr(ctx, ctx->mat[ALFD_A], A));
-  RC(download_csr(ctx, ctx->mat[ALFD_C], C));
-  RC(download_csr(ctx, ctx->mat[ALFD_CT], Ct));
+  {
+    PhaseClock pc(ctx, ALFD_SETUP_ML_FETCH);
+    RC(download_csr(ctx, ctx->mat[ALFD_A], A));
+    RC(download_csr(ctx, ctx->mat[ALFD_C], C));
+    RC(download_csr(ctx, ctx->mat[ALFD_CT], Ct));
+  }
   const int64_t lam0 = ctx->nranks > 1 ? ctx->part[last][rk] : 0;
   const int64_t lam_global = ctx->nranks > 1 ? ctx->part[last].back() : ctx->n[last];
-  if (c.ml_patch_degree > 0) RC(patch_setup(ctx, A, C, Ct));
+  if (c.ml_patch_degree > 0) {
+    PhaseClock pc(ctx, ALFD_SETUP_ML_PATCH);
+    RC(patch_setup(ctx, A, C, Ct));
+  }
   for (int l = 0; l <= nlev; ++l) {
     MlLevel &L = ctx->ml[l];
     const int64_t n = off[l][rk + 1] - off[l][rk];
@@ -3708,6 +3730,7 @@ static int ml_setup(alfd_ctx *ctx) {
       L.dinv = ctx->dinv_aug;
       L.lmax = ctx->lam_max[OP_AUG];
     } else {
+      PhaseClock pc(ctx, ALFD_SETUP_ML_LAMBDA);
       RC(ws_alloc_zero(ctx, &L.dinv, L.npad));
       RC(diag_plus_m(ctx, L.A, L.Ct, c.aug_assembled ? 0.0 : c.gamma, n, L.dinv));
       // lambda_max(D^-1 Aug_l): power iteration from the integer-hash vector (global index)
@@ -3736,14 +3759,18 @@ static int ml_setup(alfd_ctx *ctx) {
     if (!ctx->ml_P[l].rp.empty()) {
       // ---- next level through a general CSR prolongator (single rank): A_c = P^T (A P), C_c = C P, Ct_c = C_c^T
       const HostCsr &Pm = ctx->ml_P[l];
-      HostCsr AP;
-      transpose_host(Pm, R);
-      spgemm_host(A, Pm, AP);
-      spgemm_host(R, AP, An);
-      AP = HostCsr();
-      spgemm_host(C, Pm, Cn);
-      transpose_host(Cn, Ctn);
+      {
+        PhaseClock pc(ctx, ALFD_SETUP_ML_GALERKIN);
+        HostCsr AP;
+        transpose_host(Pm, R);
+        spgemm_host(A, Pm, AP);
+        spgemm_host(R, AP, An);
+        AP = HostCsr();
+        spgemm_host(C, Pm, Cn);
+        transpose_host(Cn, Ctn);
+      }
       MlLevel &Nx = ctx->ml[l + 1];
+      PhaseClock pc(ctx, ALFD_SETUP_ML_UPLOAD);
       RC(upload_level_part(ctx, Nx.A, An, nullptr, false));
       RC(upload_level_part(ctx, Nx.C, Cn, nullptr, false));
       RC(upload_level_part(ctx, Nx.Ct, Ctn, nullptr, false));
@@ -3773,6 +3800,7 @@ static int ml_setup(alfd_ctx *ctx) {
     std::vector<int32_t> aggA, aggC;
     RC(exchange_ids(ctx, dA, aggG, aggA));   // columns of A_l: [owned | halo of A_l]
     RC(exchange_ids(ctx, dC, aggG, aggC));   // columns of C_l: [owned | halo of C_l]
+    auto tg0 = std::chrono::steady_clock::now();
     galerkin(A, agg_rows.data(), w, nc_loc, aggA.data(), w, nc_glob, An);
     galerkin(C, nullptr, nullptr, C.nrows, aggC.data(), w, nc_glob, Cn);
     // Ct_{l+1} = P^T Ct_l: rows grouped by aggregate, multiplier columns back to GLOBAL ids
@@ -3794,7 +3822,9 @@ static int ml_setup(alfd_ctx *ctx) {
       P.rp[i + 1] = (int64_t)P.col.size();
     }
     transpose_host(P, R);
+    ctx->setup_s[ALFD_SETUP_ML_GALERKIN] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
     MlLevel &Nx = ctx->ml[l + 1];
+    PhaseClock pc(ctx, ALFD_SETUP_ML_UPLOAD);
     RC(upload_level_part(ctx, Nx.A, An, off[l + 1].data(), false));
     RC(upload_level_part(ctx, Nx.C, Cn, off[l + 1].data(), false));
     RC(upload_level_part(ctx, Nx.Ct, Ctn, ctx->nranks > 1 ? ctx->part[last].data() : nullptr, false));
@@ -3819,6 +3849,7 @@ static int ml_setup(alfd_ctx *ctx) {
     std::vector<double> w(ctx->n[last]);
     HIPC(hipMemcpyAsync(w.data(), ctx->diag[ALFD_INVW], w.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
+    PhaseClock pc(ctx, ALFD_SETUP_ML_COARSE);
     RC(coarse_inverse(ctx, An, Cn, Ctn, w));
   }
   if (rep_from > 0) {
@@ -3863,6 +3894,8 @@ static int ml_setup(alfd_ctx *ctx) {
 
 static int setup(alfd_ctx *ctx) {
   if (!ctx->configured) return ctx->err = "alfd_configure not called", ALFD_E_NOT_SETUP;
+  for (int ph = ALFD_SETUP_DIAG_LAMBDA; ph < ALFD_SETUP_NPHASES; ++ph) ctx->setup_s[ph] = 0.0;
+  ctx->upload_since_setup = false;
   const alfd_config &c = ctx->cfg;
   const bool rat = c.variant == ALFD_RATIONAL;
   if (rat && ctx->nranks > 1) return ctx->err = "rational variant is single-rank", ALFD_E_UNSUPPORTED;
@@ -4072,6 +4105,7 @@ static int setup(alfd_ctx *ctx) {
     return ALFD_OK;
   }
   // diag(Aug) = diag(A) + gamma sum_k w_k Ct_ik^2 (no product matrix is formed)
+  std::unique_ptr<PhaseClock> diag_clock(new PhaseClock(ctx, ALFD_SETUP_DIAG_LAMBDA));
   if (c.aug_assembled && is_elliptic(c.variant))
     return ctx->err = "aug_assembled (operator form) is implemented for the AL2 / Stokes variants", ALFD_E_UNSUPPORTED;
   RC(diag_plus(ctx, ALFD_A, ALFD_CT, c.aug_assembled ? 0.0 : c.gamma, ctx->n[0], ctx->dinv_aug));
@@ -4094,6 +4128,7 @@ static int setup(alfd_ctx *ctx) {
     RC(power_iteration(ctx, OP_AUG));
   }
   ctx->lambda_max = ctx->lam_max[c.variant == ALFD_AL_ELL_IDEAL ? OP_AUG2 : OP_AUG];
+  diag_clock.reset();
   free_levels(ctx);
   if (c.inner_prec == ALFD_PREC_MULTILEVEL) {
     if (c.variant == ALFD_AL_ELL_IDEAL)
@@ -4319,6 +4354,15 @@ int alfd_set_matrix(alfd_ctx_t ctx, int slot, int64_t nrows, int64_t ncols, cons
   ctx->is_setup = false;
   if (ctx->nranks > 1 && ctx->nblocks == 0)
     return ctx->err = "alfd_set_partition must precede alfd_set_matrix", ALFD_E_INVALID;
+  if (!ctx->upload_since_setup) ctx->setup_s[ALFD_SETUP_UPLOAD] = 0.0, ctx->upload_since_setup = true;
+  struct UploadClock {
+    alfd_ctx *c;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~UploadClock() {
+      hipStreamSynchronize(c->stream);
+      c->setup_s[ALFD_SETUP_UPLOAD] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+  } upload_clock{ctx};
   RC(upload_matrix(ctx, slot, nrows, ncols, row_ptr, col, val));
   if ((slot == ALFD_M || slot == ALFD_KIMM) && nnz <= (int64_t)1 << 26) {
     // the rational preconditioner builds its 21 shifted systems from these on the host
@@ -4519,6 +4563,18 @@ int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg) {
   ctx->cfg = *cfg;
   ctx->configured = true;
   ctx->is_setup = false;
+  return ALFD_OK;
+}
+
+int alfd_set_controls(alfd_ctx_t ctx, const alfd_control *outer, const alfd_control *inner, const alfd_control *mp_inner) {
+  CHECK_CTX();
+  if (!ctx->configured) return ctx->err = "alfd_configure not called", ALFD_E_NOT_SETUP;
+  for (const alfd_control *c : {outer, inner, mp_inner})
+    if (c && (c->kind < ALFD_CTRL_ABS || c->kind > ALFD_CTRL_FIXED_ITERS || c->max_steps < 0))
+      return ctx->err = "alfd_set_controls: bad control", ALFD_E_INVALID;
+  if (outer) ctx->cfg.outer = *outer;
+  if (inner) ctx->cfg.inner = *inner;
+  if (mp_inner) ctx->cfg.mp_inner = *mp_inner;
   return ALFD_OK;
 }
 
@@ -5158,7 +5214,17 @@ int alfd_set_row_blocks(alfd_ctx_t ctx, int slot, int64_t n_blocks, const int64_
 int alfd_enable_timing(alfd_ctx_t ctx, int on) {
   if (!ctx) return ALFD_E_INVALID;
   ctx->timing = on < 0 ? 0 : on;
-  for (int i = 0; i < ALFD_T_NCLASSES; ++i) ctx->t_ms[i] = 0, ctx->t_launches[i] = 0, ctx->t_bytes[i] = 0;
+  for (int i = 0; i < ALFD_T_NCLASSES; ++i) ctx->t_ms[i] = 0, ctx->t_launches[i] = 0, ctx->t_bytes[i] = 0, ctx->t_fbytes[i] = 0;
+  return ALFD_OK;
+}
+int alfd_get_timing_streamed(alfd_ctx_t ctx, double *streamed_bytes) {
+  if (!ctx || !streamed_bytes) return ALFD_E_INVALID;
+  for (int i = 0; i < ALFD_T_NCLASSES; ++i) streamed_bytes[i] = ctx->t_fbytes[i];
+  return ALFD_OK;
+}
+int alfd_get_setup_seconds(alfd_ctx_t ctx, double *seconds) {
+  if (!ctx || !seconds) return ALFD_E_INVALID;
+  for (int i = 0; i < ALFD_SETUP_NPHASES; ++i) seconds[i] = ctx->setup_s[i];
   return ALFD_OK;
 }
 

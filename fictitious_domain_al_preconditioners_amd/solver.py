@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "alfd_host_window_plan", "alfd_set_tunable", "alfd_build_aggregates", "alfd_get_aggregates",
     "alfd_host_aggregate_level", "alfd_comm_init_host",
     "alfd_get_device_memory", "alfd_set_row_blocks", "alfd_host_stream_plan",
-    "alfd_host_row_blocks_from_points", "alfd_host_stream_plan_short", "alfd_set_prolongator",
+    "alfd_host_row_blocks_from_points", "alfd_host_stream_plan_short", "alfd_set_prolongator", "alfd_set_controls", "alfd_get_timing_streamed", "alfd_get_setup_seconds",
 ]
 
 
@@ -95,6 +95,9 @@ def load_library():
         "alfd_set_aggregates": (C.c_int, [vp, C.c_int, i64, vp, vp, i64]),
         "alfd_set_aggregate_partition": (C.c_int, [vp, C.c_int, vp]),
         "alfd_set_prolongator": (C.c_int, [vp, C.c_int, i64, i64, vp, vp, vp]),
+        "alfd_set_controls": (C.c_int, [vp, vp, vp, vp]),
+        "alfd_get_timing_streamed": (C.c_int, [vp, vp]),
+        "alfd_get_setup_seconds": (C.c_int, [vp, vp]),
         "alfd_get_matrix_info": (C.c_int, [vp, C.c_int, C.POINTER(_abi.MatrixInfo)]),
         "alfd_bench_spmv_format": (C.c_int, [vp, C.c_int, i32, C.c_int, C.POINTER(dbl), C.POINTER(dbl)]),
         "alfd_host_window_plan": (C.c_int, [i64, vp, vp, vp, i32, i32, C.POINTER(_abi.WindowPlanInfo)]),
@@ -226,6 +229,14 @@ class Context:
         self.cfg = cfg
         self._ck(self._lib.alfd_configure(self._h, C.byref(cfg)))
 
+    def set_controls(self, outer=None, inner=None, mp_inner=None):
+        """New stop rules for the next solves, keeping the setup (alfd_set_controls)."""
+        ref = lambda c: None if c is None else C.byref(c)
+        self._ck(self._lib.alfd_set_controls(self._h, ref(outer), ref(inner), ref(mp_inner)))
+        for name, c in (("outer", outer), ("inner", inner), ("mp_inner", mp_inner)):
+            if c is not None:
+                setattr(self.cfg, name, c)
+
     def setup(self, block_sizes):
         self._ck(self._lib.alfd_setup(self._h))
         self.block_sizes = [int(b) for b in block_sizes]
@@ -352,8 +363,18 @@ class Context:
         n = np.zeros(_abi.T_NCLASSES, np.int64)
         b = np.zeros(_abi.T_NCLASSES)
         self._ck(self._lib.alfd_get_timing(self._h, ms.ctypes.data, n.ctypes.data, b.ctypes.data))
+        fb = np.zeros(_abi.T_NCLASSES)
+        self._ck(self._lib.alfd_get_timing_streamed(self._h, fb.ctypes.data))
         names = ["spmv_A", "spmv_other", "dot", "vec"]
-        return {k: dict(ms=float(ms[i]), launches=int(n[i]), bytes=float(b[i])) for i, k in enumerate(names)}
+        return {k: dict(ms=float(ms[i]), launches=int(n[i]), bytes=float(b[i]), format_bytes=float(fb[i]))
+                for i, k in enumerate(names)}
+
+    def setup_seconds(self):
+        """Wall seconds of the last uploads + setup by phase (alfd_get_setup_seconds)."""
+        s = np.zeros(8)
+        self._ck(self._lib.alfd_get_setup_seconds(self._h, s.ctypes.data))
+        names = ["upload", "diag_lambda", "ml_fetch", "ml_galerkin", "ml_upload", "ml_lambda", "ml_patch", "ml_coarse"]
+        return {k: float(s[i]) for i, k in enumerate(names)}
 
 
 class LocalGroup:

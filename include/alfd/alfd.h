@@ -334,6 +334,10 @@ int alfd_host_aggregate_level(int64_t nrows, const int64_t *row_ptr, const int32
                               int32_t block_size, double threshold, int32_t max_aggregate_nodes, int32_t *agg,
                               int64_t *n_coarse);
 int alfd_configure(alfd_ctx_t ctx, const alfd_config *cfg);
+/* New stop rules for the following solves WITHOUT a new alfd_setup (alfd_configure invalidates the setup): the
+ * reference's SolverControl objects are plain members that a caller may change between two solve() calls
+ * (outer_solver_control stokes...:282, control_lagrangian :1020-1023, control_mass :934).  NULL keeps a rule. */
+int alfd_set_controls(alfd_ctx_t ctx, const alfd_control *outer, const alfd_control *inner, const alfd_control *mp_inner);
 void alfd_default_config(alfd_config *cfg, int variant);
 /* Builds transposes, sparse-row views, diag(Aug), lambda_max, halo plans
  * (replaces the setup in stokes...:1027-1045 / utilities.h:112-331). */
@@ -474,6 +478,23 @@ enum alfd_timing_class {
 int alfd_enable_timing(alfd_ctx_t ctx, int on); /* 0 off, 1 = A-SpMV launches only, 2 = all classes */
 int alfd_get_timing(alfd_ctx_t ctx, double *ms /*[ALFD_T_NCLASSES]*/, int64_t *launches /*[..]*/,
                     double *algorithmic_bytes /*[..]*/);
+/* The same launches priced by the bytes of the storage format each kernel reads (alfd_matrix_info::streamed_bytes for
+ * the SpMV classes; equal to the algorithmic bytes for vector kernels): what a perfect cache would still move. */
+int alfd_get_timing_streamed(alfd_ctx_t ctx, double *streamed_bytes /*[ALFD_T_NCLASSES]*/);
+/* Wall seconds of the last uploads + alfd_setup by phase (host clock, device-synchronised at the phase ends): what
+ * the reference's "Solve system" timer also contains (AMG setup, factorisations: stokes...:827, immersed_laplace.cc:504). */
+enum alfd_setup_phase {
+  ALFD_SETUP_UPLOAD = 0,        /* alfd_set_matrix calls since the last alfd_setup: format planning + copies to HBM */
+  ALFD_SETUP_DIAG_LAMBDA = 1,   /* diag(Aug), lambda_max of the inner operators */
+  ALFD_SETUP_ML_FETCH = 2,      /* multilevel: host copies of the level-0 operators */
+  ALFD_SETUP_ML_GALERKIN = 3,   /* Galerkin products of all levels */
+  ALFD_SETUP_ML_UPLOAD = 4,     /* level operators, transfers: format planning + copies */
+  ALFD_SETUP_ML_LAMBDA = 5,     /* per-level diagonals and lambda_max */
+  ALFD_SETUP_ML_PATCH = 6,      /* interface-patch operators + lambda_max */
+  ALFD_SETUP_ML_COARSE = 7,     /* explicit coarsest inverse */
+  ALFD_SETUP_NPHASES = 8
+};
+int alfd_get_setup_seconds(alfd_ctx_t ctx, double *seconds /*[ALFD_SETUP_NPHASES]*/);
 
 #ifdef __cplusplus
 }

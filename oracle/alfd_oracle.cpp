@@ -1779,6 +1779,30 @@ int orc_h_precond_apply(void *h, const alfd_control *inner_override, const doubl
   return rc;
 }
 
+// One solve on a persistent handle (setup kept): bench.py's cpu_baseline / parity_prefix at the bench size.
+int orc_h_solve(void *h, const double *const *rhs, double *const *x, alfd_result *res, double *history,
+                int32_t history_cap, int32_t *history_count) {
+  orc::Problem &P = *static_cast<orc::Problem *>(h);
+  P.inner_its = P.mp_its = P.rational_its = P.mass_its = 0;
+  P.inner_failures = P.precond_applications = 0;
+  std::vector<double> bb, xx, hist;
+  pack(P, rhs, bb);
+  pack(P, x, xx);
+  std::memset(res, 0, sizeof(*res));
+  const auto t0 = std::chrono::steady_clock::now();
+  const alfd_config *cfg = &P.cfg;
+  int rc = cfg->outer_solver == ALFD_OUTER_MINRES               ? orc::minres(P, bb.data(), xx.data(), res, hist)
+           : cfg->fgmres_flavour == ALFD_FGMRES_DEALII_95 ? orc::fgmres_dealii95(P, bb.data(), xx.data(), res, hist)
+                                                          : orc::fgmres(P, bb.data(), xx.data(), res, hist);
+  res->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  unpack(P, xx, x);
+  fill_result(P, res, rc);
+  if (history_count) *history_count = (int32_t)hist.size();
+  if (history)
+    for (int i = 0; i < (int)hist.size() && i < history_cap; ++i) history[i] = hist[i];
+  return rc;
+}
+
 int orc_h_system_apply(void *h, const double *const *src, double *const *dst) {
   orc::Problem &P = *static_cast<orc::Problem *>(h);
   std::vector<double> u, v(P.ntot(), 0.0);

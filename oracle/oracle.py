@@ -63,6 +63,8 @@ def lib():
         l.orc_close.argtypes = [C.c_void_p]
         l.orc_h_precond_apply.restype = C.c_int
         l.orc_h_precond_apply.argtypes = [C.c_void_p, C.POINTER(_abi.Control), PP, PP, C.POINTER(_abi.Result)]
+        l.orc_h_solve.restype = C.c_int
+        l.orc_h_solve.argtypes = [C.c_void_p, PP, PP, C.POINTER(_abi.Result), C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         l.orc_h_system_apply.restype = C.c_int
         l.orc_h_system_apply.argtypes = [C.c_void_p, PP, PP]
         l.orc_set_threads.restype = C.c_int
@@ -181,6 +183,16 @@ class OracleSystem:
         rc = lib().orc_h_precond_apply(h, C.byref(inner) if inner is not None else None, _blocks(src),
                                        _blocks(dst), C.byref(res))
         return rc, dst, res
+
+    def handle_solve(self, h, rhs, x0=None, history_cap=4096):
+        """One solve on a persistent handle (setup kept); returns (rc, x, result, history)."""
+        rhs = self._check(rhs)
+        x = [np.zeros(n) for n in self.block_sizes] if x0 is None else [b.copy() for b in self._check(x0)]
+        res = _abi.Result()
+        hist = np.zeros(history_cap)
+        cnt = C.c_int32(0)
+        rc = lib().orc_h_solve(h, _blocks(rhs), _blocks(x), C.byref(res), hist.ctypes.data, history_cap, C.byref(cnt))
+        return rc, x, res, hist[:min(cnt.value, history_cap)].copy()
 
     def handle_system_apply(self, h, src):
         src = self._check(src)

@@ -45,7 +45,7 @@ def test_version_strerror_and_default_config_mirror():
     c = _abi.default_config(_abi.AL_STOKES)
     assert (c.restart, c.inner.max_steps, c.inner.tol, c.inner.kind) == (30, 100, 1e-2, _abi.CTRL_ABS)
     assert _abi.default_config(_abi.AL_ELL_MODIFIED).restart == 50
-    assert C.sizeof(_abi.Config) == 248 and C.sizeof(_abi.Result) == 80
+    assert C.sizeof(_abi.Config) == 264 and C.sizeof(_abi.Result) == 80
     assert C.sizeof(_abi.MatrixInfo) == 88 and C.sizeof(_abi.WindowPlanInfo) == 88
 
 

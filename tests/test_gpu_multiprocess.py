@@ -39,12 +39,28 @@ def test_partitioned_solve_in_separate_processes_over_gloo(built, world, mode):
     assert out["ok"] and out["world"] == world and out["outer"] > 0
 
 
+def test_bench_starts_its_own_ranks(built):
+    """`python bench.py --gpus 2` WITHOUT a launcher (how a driver may call it): bench.py starts the two ranks as child
+    processes before touching the GPU and relays rank 0's line.  One-GPU box: both ranks on device 0, host transport."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", ALFD_BENCH_SINGLE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "host", "--n-cells", "12",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--general-steps", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["outer_iterations_per_solve"] > 0
+    assert out["config"]["transport"] == "host buffers over gloo"
+
+
 def test_two_gpu_rccl_bench_matches_single_gpu_counts(built):
     """The literal RCCL path (ncclAllGather / grouped ncclSend+ncclRecv) needs two devices."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("fewer than 2 GPUs visible: RCCL cannot place two ranks on one device")
-    args = ["--n-cells", "16", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    args = ["--n-cells", "16", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--hierarchy", "aggregation",
+            "--general-steps", "0"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True,
                          text=True, timeout=900, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-3000:]

@@ -503,12 +503,13 @@ def test_properties_at_bench_scale(built):
     properties the domain offers."""
     n = int(os.environ.get("ALFD_TEST_FULL_NCELLS", "74"))
     pb = problems.stokes3d_sphere(n, 4 if n >= 48 else 3)
-    cfg = _abi.default_config(_abi.AL_STOKES)
-    cfg.inner.max_steps = 2000
-    cfg.inner_prec = _abi.PREC_MULTILEVEL
-    cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
-    ctx = solver.context_from_problem(pb, cfg, aggregates=problems.geometric_aggregates(pb, a=2),
-                                      row_blocks=problems.brick_row_blocks(pb.params, (16, 4, 1)))   # as bench.py
+    # bench.py's exact solver settings (one definition: _abi.bench_multilevel_settings): geometric hierarchy,
+    # Chebyshev(3)/30 + degree 5 below, interface patch 20/400, explicit coarsest inverse, inner cap 100
+    # (parameters_stokes_3d.prm:23-24), prolongators down to BENCH_MIN_COARSE, 16x4x1 mesh bricks
+    cfg = _abi.bench_multilevel_settings(_abi.default_config(_abi.AL_STOKES), geometric=True)
+    ctx = solver.context_from_problem(pb, cfg, aggregates=problems.tensor_prolongators(pb.params, min_coarse=_abi.BENCH_MIN_COARSE),
+                                      row_blocks=problems.brick_row_blocks(pb.params, (16, 4, 1)))
+    assert ctx.matrix_info(_abi.A)["batch_major"] == 2
     rng = np.random.default_rng(0)
     xs = [[rng.uniform(-1, 1, n_) for n_ in pb.block_sizes] for _ in range(2)]
     a, b = 0.75, -1.25
@@ -538,10 +539,42 @@ def test_properties_at_bench_scale(built):
     r = np.sqrt(sum(float(np.dot(p_ - q_, p_ - q_)) for p_, q_ in zip(rhs, axx)))
     assert res.status == 0 and r <= 2 * max(cfg.outer.tol, cfg.outer.reduce * res.initial_residual)
     assert 5 <= res.outer_iterations <= 15
+    assert res.inner_iterations <= 12 * res.outer_iterations     # the reference's cap is 100 per application (prm:23)
     x2, res2 = ctx.solve(rhs)
     assert np.array_equal(ctx.history(), h1) and all(np.array_equal(p_, q_) for p_, q_ in zip(x, x2))
     assert np.all(np.diff(h1) <= 0)
     ctx.close()
+
+
+def test_mid_size_solve_with_the_bench_kernels_matches_oracle(built):
+    """Solve-level oracle parity at a size where the kernels of the bench are the ones that run: N = 20 Taylor-Hood
+    (0.21 M velocity rows) on 16x4x1 mesh bricks with bench.py's multigrid settings -- the batch-major long-row kernel
+    (spmv_vs_kernel) on A and the batch-major short-row kernel (spmv_vss_kernel) on the coupling blocks sit INSIDE a
+    solve whose iteration counts and residual history are compared with the oracle's."""
+    n = 20
+    pb = problems.stokes3d_sphere(n, 2)
+    cfg = _abi.bench_multilevel_settings(_abi.default_config(_abi.AL_STOKES), geometric=True)
+    levels = problems.tensor_prolongators(pb.params, min_coarse=_abi.BENCH_MIN_COARSE)
+    ctx = solver.context_from_problem(pb, cfg, aggregates=levels, row_blocks=problems.brick_row_blocks(pb.params, (16, 4, 1)))
+    try:
+        info = ctx.matrix_info(_abi.A)
+        assert info["batch_major"] == 2 and info["lanes"] == 64
+        short = [s for s in (_abi.BT, _abi.B, _abi.MP) if ctx.matrix_info(s)["batch_major"] and ctx.matrix_info(s)["lanes"] < 64]
+        assert short, "no short-row operator landed on the batch-major form at this size"
+        osys = oracle.system_from_problem(pb, aggregates=levels)
+        rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+        assert rc == 0
+        x, res = ctx.solve(rhs)
+        hist = ctx.history()
+        rc, ox, ores, ohist = osys.solve(cfg, rhs)
+        assert rc == 0 and res.status == 0
+        assert (res.outer_iterations, res.inner_iterations, res.mp_iterations) == \
+               (ores.outer_iterations, ores.inner_iterations, ores.mp_iterations)
+        assert len(hist) == len(ohist) and np.max(np.abs(hist - ohist) / np.abs(ohist)) <= HIST_RTOL
+        for g, r in zip(x, ox):
+            assert np.allclose(g, r, rtol=1e-9, atol=1e-10 * max(np.abs(r).max(), 1e-30))
+    finally:
+        ctx.close()
 
 
 def _full_size_properties(pb, cfg, rhs, aggs, outer_band, symmetric, augment, scipy_rows=None, row_blocks=None):
