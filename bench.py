@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--comm", choices=["rccl", "host"], default=os.environ.get("ALFD_BENCH_COMM", "rccl"),
                     help="multi-GPU transport: RCCL over xGMI (default) or host buffers through a gloo group "
                          "(alfd_comm_init_host; slower, for boxes where RCCL cannot start)")
+    ap.add_argument("--reference-shaped-n", type=int, default=int(os.environ.get("ALFD_BENCH_REFSHAPE_N", "64")),
+                    help="cells per direction of the reference-shaped leg (cell-wise assembled block (0,0) in a Cuthill-McKee "
+                         "numbering, as handed over and after the front end's renumbering); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only-spmv", type=int, default=0,
                     help="skip the solve; run this many back-to-back A SpMV launches (for rocprofv3)")
@@ -415,6 +418,8 @@ def main():
         "general_matrix_leg": general,
         "no_translate_sharing_leg": unshared,
     }
+    if world == 1 and args.reference_shaped_n > 0 and args.inner_prec == "multilevel" and geometric:
+        out["reference_shaped_leg"] = reference_shaped_leg(args.reference_shaped_n, cfg, args.bricks)
 
     # ----------------------------------------------------------- CPU baseline + parity at the size the bench runs
     rc_exit = 0
@@ -451,6 +456,75 @@ def main():
         dist.destroy_process_group()
     if rc_exit:
         raise SystemExit(rc_exit)
+
+
+def reference_shaped_leg(n, cfg, bricks):
+    """What an operator shaped like the reference's gets.  The reference assembles cell by cell
+    (stokes_immersed_boundary.cc:668-760) on hyper_cube meshes of 2^k cells per direction and numbers its DoFs with
+    Cuthill-McKee, then block-wise (:533-541).  Here: block (0,0) from ONE numerically integrated cell matrix whose
+    contributions are summed in Morton order of the cells (mathematically equal entries then differ in their last
+    bits: 720 instead of 285 distinct values), nodes renumbered by Cuthill-McKee; solved with the bench's settings
+    (a) exactly as handed over, no hint, (b) after the front end's renumbering from support points
+    (alfd_host_numbering_from_points + alfd_host_brick_blocks_from_points, what dealii_adapter.hpp / solver.py do
+    before the upload).  The same-size Kronecker / lexicographic operator of the headline is the yardstick."""
+    import numpy as np
+    from fictitious_domain_al_preconditioners_amd import _abi, problems, solver
+
+    refine = max(0, int(round(np.log2(n / 64.0))) + 4)
+    brick = tuple(int(v) for v in bricks.split(",")) if bricks != "0" else (16, 4, 1)
+    c = _abi.Config.from_buffer_copy(cfg)
+    c.log_level = 0
+
+    def measure(pb, blocks, what):
+        perm = getattr(pb, "node_permutation", None)
+        levels = problems.tensor_prolongators(pb.params, min_coarse=_abi.BENCH_MIN_COARSE, node_permutation=perm)
+        ctx = solver.Context(0)
+        t0 = time.time()
+        solver.upload_problem(ctx, pb, c, levels, blocks)
+        t_up = time.time() - t0
+        info = ctx.matrix_info(_abi.A)
+        rhs = ctx.augment_rhs([pb.vecs["f"], pb.vecs["rhs_p"], pb.vecs["g"]])
+        ctx.upload_rhs(rhs)
+        ctx.solve_resident()
+        ctx.enable_timing(True)
+        res = ctx.solve_resident()
+        t = ctx.timing()["spmv_A"]
+        ctx.enable_timing(False)
+        ctx.close()
+        return {"what": what,
+                "storage": ("batch-major" + (" (10-bit codes)" if info["batch_major_wide"] else "") if info["batch_major"]
+                            else "value-indexed window" if info["value_indexed"] else "window 10 B/nnz" if info["windowed"] else "csr"),
+                "shared_share": info["shared_nnz"] / max(info["nnz"], 1),
+                "bytes_per_nnz": info["streamed_bytes"] / max(info["nnz"], 1),
+                "spmv_A_ms": t["ms"] / max(t["launches"], 1), "upload_setup_s": t_up,
+                "outer": res.outer_iterations, "inner": res.inner_iterations, "solve_s": res.solve_seconds,
+                "value": res.outer_iterations / res.solve_seconds, "unit": "iterations/s"}
+
+    t0 = time.time()
+    legs = {}
+    pb = problems.stokes3d_sphere(n_cells=n, immersed_refine=refine)
+    legs["kronecker_lexicographic"] = measure(pb, problems.brick_row_blocks(pb.params, brick),
+                                              "the headline's operator at this size (closed-form rows, node-major lexicographic, mesh bricks)")
+    del pb
+    pb = problems.stokes3d_sphere(n_cells=n, immersed_refine=refine, assembly="cellwise")
+    problems.permute_background_nodes(pb, problems.cuthill_mckee_nodes(pb))
+    legs["cellwise_cuthill_mckee_as_handed_over"] = measure(pb, None, "cell-wise sums, Cuthill-McKee numbering, uploaded as is (no hint)")
+    tf = time.time()
+    pts = problems.row_support_points(pb.params, node_permutation=pb.node_permutation)
+    n2o = solver.numbering_from_points(pts)
+    nc = pb.params["ncomp"]
+    problems.permute_background_nodes(pb, n2o[::nc] // nc)
+    pts = problems.row_support_points(pb.params, node_permutation=pb.node_permutation)
+    blocks = solver.brick_blocks_from_points(pts, brick)
+    t_front = time.time() - tf
+    legs["cellwise_cuthill_mckee_front_end_renumbered"] = measure(
+        pb, blocks, "the same operator after the front end's renumbering from support points + mesh bricks from the points")
+    legs["cellwise_cuthill_mckee_front_end_renumbered"]["front_end_s"] = t_front
+    base = legs["kronecker_lexicographic"]["value"]
+    for v in legs.values():
+        v["fraction_of_kronecker_lexicographic"] = v["value"] / base
+    log(f"reference-shaped leg (N={n}) in {time.time()-t0:.1f} s: " + ", ".join(f"{k} {v['value']:.2f} it/s" for k, v in legs.items()))
+    return {"n_cells": n, "dofs_velocity": int(3 * (2 * n + 1) ** 3), "legs": legs}
 
 
 def load_pmc(n_cells, info, bricks, world):

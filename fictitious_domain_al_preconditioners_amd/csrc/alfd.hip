@@ -102,6 +102,7 @@ struct DevCsr {
     int64_t nb = 0, nseg = 0, stream_bytes = 0, nbatch = 0, dict_total = 0, shared_nnz = 0;
     int32_t stride = 0, maxW = 0;
     int32_t L = 64, tab_u64 = 8;   // lanes per row of the format; descriptor words per batch
+    int32_t wide = 0;              // 10-bit codes / 11-bit window columns (VsFmt<1>)
     uint8_t *stream = nullptr;
     int64_t *sb = nullptr;
     uint64_t *tab = nullptr;
@@ -288,7 +289,7 @@ struct alfd_ctx {
   int win_RB_vi = 96;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
   int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
-  int vs_enable = 1, vs_NW = 4, vs_RB = 96, vs_xcd = 0, vs_share = 1;   // batch-major format (alfd_set_tunable "batch_major")
+  int vs_enable = 1, vs_NW = 4, vs_RB = 96, vs_xcd = 0, vs_share = 1, vs_wide = 1;   // batch-major format (alfd_set_tunable "batch_major")
   std::vector<int64_t> rb_ptr[ALFD_NSLOTS + 1];   // row-block hint per slot (alfd_set_row_blocks)
   std::vector<int32_t> rb_rows[ALFD_NSLOTS + 1];
   int win_short_min_blocks = 256;           // the same for short-row matrices (ALFD_SPMV_WINDOW_SHORT_MIN_BLOCKS; 64 costs cfg 3 30 %, 1024 leaves its 262 k-row level operator out)
@@ -690,13 +691,16 @@ static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y
   if (v.L == 16) return launch_vss<16>(ctx, m, x, y, epi, alpha, d, y2), true;
   if (v.L == 8) return launch_vss<8>(ctx, m, x, y, epi, alpha, d, y2), true;
   const int NW = ctx->vs_NW;
-  const size_t lds = (size_t)kVsWinOff + (size_t)v.maxW * sizeof(double);
+  const size_t lds = (size_t)(v.wide ? VsFmt<1>::kWinOff : VsFmt<0>::kWinOff) + (size_t)v.maxW * sizeof(double);
 #define ALFD_VS_ARGS                                                                                          \
   v.stream, v.sb, v.tab, v.cnt, v.stride, v.seg_begin, v.blkW, v.seg_col, v.seg_off, v.doff, v.dn, v.dict, x, \
       m.halo, m.n_local_cols, y, alpha, d, y2, ctx->vs_xcd
 #define ALFD_VS(EPI, NWV)                                                                                        \
   do {                                                                                                           \
-    if (m.tag == 0)                                                                                              \
+    if (v.wide) /* 10-bit codes: one instantiation per epilogue (4 waves) */                                    \
+      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, 4, 1>), dim3((unsigned)v.nb), dim3(256), lds, ctx->stream,     \
+                         ALFD_VS_ARGS);                                                                          \
+    else if (m.tag == 0)                                                                                         \
       hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, NWV>), dim3((unsigned)v.nb), dim3(64 * NWV), lds, ctx->stream, \
                          ALFD_VS_ARGS);                                                                          \
     else /* multigrid level matrix: its own instantiation, so that profiles keep the two apart */               \
@@ -1960,6 +1964,8 @@ struct VsPlan {
   std::vector<int64_t> sb;
   std::vector<uint8_t> stream;
   std::vector<uint64_t> tab;
+  int wide = 0;       // 1: 10-bit codes / 11-bit window columns (VsFmt<1>)
+  int64_t nb_in = 0;  // blocks before the dictionary limit halved any
 };
 
 struct VsBatch {
@@ -2110,7 +2116,7 @@ static int64_t vs_batch_units(const VsBatch &q, const std::vector<int32_t> &rows
 // kVsMaxRows rows, are halved until they fit; false if a single row does not fit.
 static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val, int RB, int64_t nb_in,
                              const int64_t *bptr, const int32_t *brows, std::vector<int64_t> &optr,
-                             std::vector<int32_t> &orows, int max_rows = kVsMaxRows) {
+                             std::vector<int32_t> &orows, int max_rows = kVsMaxRows, int max_dict = kVsMaxDict) {
   const bool nat = bptr == nullptr;
   const int64_t nb = nat ? (nrows + RB - 1) / RB : nb_in;
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -2125,7 +2131,7 @@ static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val
   std::vector<std::thread> th;
   for (int t = 0; t < T; ++t)
     th.emplace_back([&, t]() {
-      constexpr int kTab = 1024;   // open addressing over the 64-bit patterns; stamps avoid clearing
+      constexpr int kTab = 4096;   // open addressing over the 64-bit patterns; stamps avoid clearing
       std::vector<uint64_t> keys(kTab);
       std::vector<uint32_t> stamp(kTab, 0);
       uint32_t gen = 0;
@@ -2146,12 +2152,12 @@ static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val
               for (int64_t k = rp[r]; k < rp[r + 1] && fits; ++k) {
                 uint64_t bits;
                 std::memcpy(&bits, &val[k], 8);
-                uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
+                uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 52);
                 while (stamp[h] == gen && keys[h] != bits) h = (h + 1) & (kTab - 1);
                 if (stamp[h] != gen) {
                   stamp[h] = gen;
                   keys[h] = bits;
-                  fits = ++distinct <= kVsMaxDict;
+                  fits = ++distinct <= max_dict;
                 }
               }
             }
@@ -2180,10 +2186,14 @@ static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val
 
 static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int RB, int maxW,
                     int GAP, int64_t nb_in, const int64_t *bptr_in, const int32_t *brows_in, VsPlan &pl,
-                    bool share = true) {
+                    bool share = true, int wide = 0) {
   std::vector<int64_t> r_ptr;
   std::vector<int32_t> r_rows;
-  if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, nb_in, bptr_in, brows_in, r_ptr, r_rows)) return;
+  const int max_dict = wide ? VsFmt<1>::kMaxDict : VsFmt<0>::kMaxDict, code_shift = wide ? VsFmt<1>::kCodeShift : VsFmt<0>::kCodeShift;
+  maxW = std::min(maxW, wide ? VsFmt<1>::kMaxSlots : VsFmt<0>::kMaxSlots);
+  pl.wide = wide;
+  pl.nb_in = nb_in > 0 ? nb_in : (nrows + RB - 1) / RB;
+  if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, nb_in, bptr_in, brows_in, r_ptr, r_rows, kVsMaxRows, max_dict)) return;
   const int64_t *bptr = r_ptr.data();
   const int32_t *brows = r_rows.data();
   const int64_t nb = (int64_t)r_ptr.size() - 1;
@@ -2251,7 +2261,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
       th.emplace_back([&, t]() {
         std::vector<int32_t> rows;
         VsWindow w;
-        constexpr int kTab = 1024;
+        constexpr int kTab = 4096;
         std::vector<uint64_t> keys(kTab);
         std::vector<int16_t> ids(kTab);
         for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
@@ -2270,10 +2280,10 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
           auto field_of = [&](int64_t k) -> int64_t {   // (code << 15) | (window slot << 3) of CSR entry k; -1: dictionary full
             uint64_t bits;
             std::memcpy(&bits, &val[k], 8);
-            uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 54);
+            uint32_t h = (uint32_t)((bits * 0x9E3779B97F4A7C15ull) >> 52);
             for (;;) {
               if (ids[h] < 0) {
-                if (t_dict[t].size() - d0 == (size_t)kVsMaxDict) return -1;
+                if (t_dict[t].size() - d0 == (size_t)max_dict) return -1;
                 keys[h] = bits;
                 ids[h] = (int16_t)(t_dict[t].size() - d0);
                 t_dict[t].push_back(val[k]);
@@ -2282,7 +2292,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
               if (keys[h] == bits) break;
               h = (h + 1) & (kTab - 1);
             }
-            return ((int64_t)ids[h] << 15) | ((int64_t)w.pos[col[k] - w.clo] << 3);
+            return ((int64_t)ids[h] << code_shift) | ((int64_t)w.pos[col[k] - w.clo] << 3);
           };
           for (size_t q = 0; q < bts.size() && !bad; ++q) {
             const VsBatch &bt = bts[q];
@@ -2566,6 +2576,17 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
   } else {
     plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pl, ctx->vs_share != 0);
   }
+  if (ctx->vs_wide && (!pl.ok || pl.nb > pl.nb_in)) {
+    // blocks with more than 512 distinct values had to be halved (or the plan failed): the same blocks with 10-bit
+    // codes and 11-bit window columns, kept if the stream gets smaller
+    VsPlan pw;
+    if (hint)
+      plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, (int64_t)ctx->rb_ptr[slot].size() - 1,
+              ctx->rb_ptr[slot].data(), ctx->rb_rows[slot].data(), pw, ctx->vs_share != 0, 1);
+    else
+      plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pw, ctx->vs_share != 0, 1);
+    if (pw.ok && (!pl.ok || pw.stream.size() + 64 * (size_t)pw.nbatch < pl.stream.size() + 64 * (size_t)pl.nbatch)) pl = std::move(pw);
+  }
   if (!pl.ok) return ALFD_OK;
   DevCsr::Vs &v = m.vs;
   RC(upload_vec(ctx, m, &v.stream, pl.stream));
@@ -2588,12 +2609,13 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
   v.dict_total = (int64_t)pl.dict.size();
   v.stride = pl.stride;
   v.maxW = pl.maxW;
+  v.wide = pl.wide;
   v.bricks = hint;
   v.on = true;
   if (ctx->cfg.log_level > 0)
     std::fprintf(stderr,
-                 "[alfd] batch-major format: %lld blocks (%s), %lld batches, window <= %d slots, %.2f B/nnz, %.1f %% of the "
-                 "entries in template-shared batches\n",
+                 "[alfd] batch-major format%s: %lld blocks (%s), %lld batches, window <= %d slots, %.2f B/nnz, %.1f %% of the "
+                 "entries in template-shared batches\n", pl.wide ? " (10-bit codes)" : "",
                  (long long)pl.nb, hint ? "caller's row blocks" : "runs of the numbering", (long long)pl.nbatch, pl.maxW,
                  (double)v.stream_bytes / (double)std::max<int64_t>(m.nnz, 1),
                  100.0 * (double)pl.shared_nnz / (double)std::max<int64_t>(m.nnz, 1));
@@ -2764,7 +2786,9 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
                          m.nrows >= (int64_t)std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / m.L) * ctx->win_short_min_blocks;
   if (ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0)
     RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot));
-  if (ctx->vs_enable && m.vi && m.L == 64) RC(build_vs(ctx, m, slot, rp, col_up, val));
+  // the batch-major form has dictionaries of its own (per row block, up to 1024 values with wide codes): it is tried
+  // even when the 96-row window blocks above could not be coded (cell-wise assembled operators)
+  if (ctx->vs_enable && m.win && (m.vi || ctx->vs_wide) && m.L == 64) RC(build_vs(ctx, m, slot, rp, col_up, val));
   if (ctx->vs_enable && m.win && (m.L == 32 || m.L == 16 || m.L == 8)) RC(build_vss(ctx, m, rp, col_up, val));
   m.present = true;
   return ALFD_OK;
@@ -4879,7 +4903,7 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   std::memset(out, 0, sizeof(*out));
   out->lanes = m.L;
   out->windowed = m.win ? 1 : 0;
-  out->value_indexed = m.vi ? 1 : 0;
+  out->value_indexed = (m.vi || (m.vs.on && ctx->vs_enable)) ? 1 : 0;
   out->batch_major = (m.vs.on && ctx->vs_enable) ? (m.vs.bricks ? 2 : 1) : 0;
   out->nnz = m.nnz;
   out->window_blocks = m.win_nblocks;
@@ -4890,6 +4914,9 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   out->value_wide_nnz = m.vi_wide_nnz;
   out->algorithmic_bytes = m.algorithmic_bytes();
   out->streamed_bytes = m.streamed_bytes(true, ctx->vs_enable != 0);
+  out->shared_nnz = m.vs.on ? m.vs.shared_nnz : 0;
+  out->batch_major_blocks = m.vs.on ? m.vs.nb : 0;
+  out->batch_major_wide = m.vs.on ? m.vs.wide : 0;
   return ALFD_OK;
 }
 
@@ -5032,6 +5059,13 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
   VsPlan pl;
   if (n_blocks > 0) plan_vs(nrows, rp, col, val, row_block, 4096, 8, n_blocks, block_ptr, rows, pl);
   else plan_vs(nrows, rp, col, val, row_block, 4096, 8, 0, nullptr, nullptr, pl);
+  if (!pl.ok || pl.nb > pl.nb_in) {   // as build_vs: wide codes when the 512-value limit halved blocks
+    VsPlan pw;
+    if (n_blocks > 0) plan_vs(nrows, rp, col, val, row_block, 4096, 8, n_blocks, block_ptr, rows, pw, true, 1);
+    else plan_vs(nrows, rp, col, val, row_block, 4096, 8, 0, nullptr, nullptr, pw, true, 1);
+    if (pw.ok && (!pl.ok || pw.stream.size() + 64 * (size_t)pw.nbatch < pl.stream.size() + 64 * (size_t)pl.nbatch)) pl = std::move(pw);
+  }
+  const int code_shift = pl.wide ? VsFmt<1>::kCodeShift : VsFmt<0>::kCodeShift;
   out->ok = pl.ok ? 1 : 0;
   if (!pl.ok) return ALFD_OK;
   out->max_window = pl.maxW;
@@ -5086,8 +5120,8 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
             f = cell[0] | ((uint32_t)cell[1] << 8) | ((uint32_t)cell[2] << 16);
           }
           if ((f & 7u) || (f >> 24)) ++bad;
-          const int32_t lcv = (int32_t)((f >> 3) & 0xfffu) + shift / 8;
-          const uint32_t vcv = f >> 15;
+          const int32_t lcv = (int32_t)((f >> 3) & ((1u << (code_shift - 3)) - 1u)) + shift / 8;
+          const uint32_t vcv = f >> code_shift;
           const double v = (int32_t)vcv < pl.dn[b] ? pl.dict[pl.doff[b] + vcv] : std::nan("");
           const int32_t c = (lcv >= 0 && lcv < pl.blkW[b]) ? slot_col[lcv] : -1;
           if (c != col[rp[r] + k] || std::memcmp(&v, &val[rp[r] + k], 8) != 0) ++bad;
@@ -5161,6 +5195,92 @@ int alfd_host_stream_plan_short(int64_t nrows, const int64_t *rp, const int32_t 
   return ALFD_OK;
 }
 
+int alfd_host_numbering_from_points(int64_t nrows, int32_t dim, const double *points, int64_t *new_to_old) {
+  if (nrows < 0 || dim < 1 || dim > 3 || !points || !new_to_old) return ALFD_E_INVALID;
+  for (int64_t i = 0; i < nrows; ++i) new_to_old[i] = i;
+  std::stable_sort(new_to_old, new_to_old + nrows, [&](int64_t a, int64_t b) {
+    for (int d = dim - 1; d >= 0; --d) {
+      const double pa = points[a * dim + d], pb = points[b * dim + d];
+      if (pa != pb) return pa < pb;
+    }
+    return false;
+  });
+  return ALFD_OK;
+}
+
+int alfd_host_brick_blocks_from_points(int64_t nrows, int32_t dim, const double *points, const int32_t *brick,
+                                       int32_t max_rows, int64_t *n_blocks_out, int64_t *block_ptr_out, int32_t *rows_out) {
+  if (nrows < 0 || dim < 1 || dim > 3 || !points || !brick || max_rows < 1 || max_rows > kVsMaxRows || !n_blocks_out ||
+      !block_ptr_out || !rows_out || nrows > 2147483000LL)
+    return ALFD_E_INVALID;
+  for (int d = 0; d < dim; ++d)
+    if (brick[d] < 1) return ALFD_E_INVALID;
+  // grid index of a point along an axis = rank of its coordinate among the distinct coordinates of the axis
+  std::vector<std::vector<int32_t>> gi(dim, std::vector<int32_t>(nrows));
+  int64_t span[3] = {1, 1, 1};
+  for (int d = 0; d < dim; ++d) {
+    std::vector<double> u(nrows);
+    for (int64_t i = 0; i < nrows; ++i) u[i] = points[i * dim + d];
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    for (int64_t i = 0; i < nrows; ++i)
+      gi[d][i] = (int32_t)(std::lower_bound(u.begin(), u.end(), points[i * dim + d]) - u.begin());
+    span[d] = (int64_t)u.size() / brick[d] + 1;
+  }
+  std::vector<std::pair<int64_t, int32_t>> key(nrows);   // (brick id, row): rows of a brick in ascending order
+  for (int64_t i = 0; i < nrows; ++i) {
+    int64_t k = 0;
+    for (int d = dim - 1; d >= 0; --d) k = k * span[d] + gi[d][i] / brick[d];
+    key[i] = {k, (int32_t)i};
+  }
+  std::sort(key.begin(), key.end());
+  int64_t nb = 0;
+  block_ptr_out[0] = 0;
+  for (int64_t i = 0; i < nrows;) {
+    int64_t j = i;
+    while (j < nrows && key[j].first == key[i].first) ++j;
+    for (int64_t a = i; a < j; a += max_rows) block_ptr_out[++nb] = std::min<int64_t>(a + max_rows, j);
+    i = j;
+  }
+  for (int64_t i = 0; i < nrows; ++i) rows_out[i] = key[i].second;
+  *n_blocks_out = nb;
+  return ALFD_OK;
+}
+
+int alfd_host_permute_csr(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val,
+                          const int64_t *row_new_to_old, const int64_t *col_old_to_new, int64_t *orp, int32_t *ocol,
+                          double *oval) {
+  if (nrows < 0 || !rp || !orp || (rp[nrows] > 0 && (!col || !val || !ocol || !oval))) return ALFD_E_INVALID;
+  orp[0] = 0;
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int64_t src = row_new_to_old ? row_new_to_old[r] : r;
+    if (src < 0 || src >= nrows) return ALFD_E_INVALID;
+    orp[r + 1] = orp[r] + (rp[src + 1] - rp[src]);
+  }
+  if (orp[nrows] != rp[nrows]) return ALFD_E_INVALID;   // row_new_to_old is not a permutation
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                                           (nrows + 8191) / 8192));
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() {
+      std::vector<std::pair<int32_t, double>> row;
+      for (int64_t r = nrows * t / T; r < nrows * (t + 1) / T; ++r) {
+        const int64_t src = row_new_to_old ? row_new_to_old[r] : r;
+        const int64_t k0 = rp[src], len = rp[src + 1] - k0, o0 = orp[r];
+        if (!col_old_to_new) {
+          for (int64_t k = 0; k < len; ++k) ocol[o0 + k] = col[k0 + k], oval[o0 + k] = val[k0 + k];
+          continue;
+        }
+        row.resize(len);
+        for (int64_t k = 0; k < len; ++k) row[k] = {(int32_t)col_old_to_new[col[k0 + k]], val[k0 + k]};
+        std::sort(row.begin(), row.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        for (int64_t k = 0; k < len; ++k) ocol[o0 + k] = row[k].first, oval[o0 + k] = row[k].second;
+      }
+    });
+  for (auto &x : th) x.join();
+  return ALFD_OK;
+}
+
 int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_bytes) {
   CHECK_CTX();
   size_t f = 0, t = 0;
@@ -5182,6 +5302,10 @@ int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value) {
   }
   if (std::strcmp(name, "batch_major_share") == 0) {   // 0: no template-shared batches (takes effect at the next alfd_set_matrix)
     ctx->vs_share = value != 0;
+    return ALFD_OK;
+  }
+  if (std::strcmp(name, "batch_major_wide") == 0) {   // 0: never plan 10-bit codes (at the next alfd_set_matrix)
+    ctx->vs_wide = value != 0;
     return ALFD_OK;
   }
   if (std::strcmp(name, "batch_major_waves") == 0) {

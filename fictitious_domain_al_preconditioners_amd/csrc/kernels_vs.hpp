@@ -34,6 +34,20 @@ constexpr int kVsMaxDict = 512;   // distinct values per block (9-bit codes)
 constexpr int kVsDictOff = 0;     // the block's dictionary at LDS offset 0
 constexpr int kVsWinOff = kVsMaxDict * 8;   // the x window behind it (at most 4096 slots: 12-bit columns)
 constexpr int kVsMaxRows = 250;   // rows per block
+// Field layout of an entry.  WD = 0: 9-bit dictionary code, 12-bit window column (512 values, 4096 slots per block);
+// WD = 1 ("wide codes"): 10-bit code, 11-bit column (1024 values, 2048 slots) -- for operators whose blocks hold more
+// than 512 distinct values, e.g. cell-wise assembled matrices whose mathematically equal entries differ in their last
+// bits with the visiting order of the cells (720 instead of 285 distinct values in the Stokes velocity block).
+template <int WD>
+struct VsFmt {
+  static constexpr uint32_t kColMask = WD ? 0x3ff8u : 0x7ff8u;
+  static constexpr int kDictShift = WD ? 11 : 12;
+  static constexpr uint32_t kDictMask = WD ? 0x1ff8u : 0xff8u;
+  static constexpr int kWinOff = WD ? 8192 : 4096;
+  static constexpr int kCodeShift = WD ? 14 : 15;    // host side: field = (code << kCodeShift) | (slot << 3)
+  static constexpr int kMaxDict = WD ? 1024 : 512;
+  static constexpr int kMaxSlots = WD ? 2048 : 4096;
+};
 constexpr int kVsMaxLen = 384;    // longest row the format takes (class 6)
 
 // batch descriptor: 8 x uint64, one per row: eb (20 bits) | entry count (9) | class = ceil(count / 64) (3)
@@ -62,7 +76,7 @@ struct VsWord3 {
 // partial: only lanes below the batch's longest remainder are stored (rows of a class are sorted by
 // length, so the remainders of a batch are equal or close); rem[i] masks row i's fma.
 // All loads of the batch are issued before the first use.
-template <int NCH>
+template <int NCH, int WD>
 __device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem, int lane,
                                          const uint8_t *__restrict__ fb, const char *sm, double (&acc)[4]) {
   VsWord3 w[NCH];
@@ -76,8 +90,8 @@ __device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem
                            __builtin_amdgcn_alignbit(w[j].z, w[j].y, 16), w[j].z >> 8};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      xv[i] = vs_lds_f64(kVsWinOff + (f[i] & 0x7ff8u));
-      v[i] = vs_lds_f64(kVsDictOff + ((f[i] >> 12) & 0xff8u));
+      xv[i] = vs_lds_f64(VsFmt<WD>::kWinOff + (f[i] & VsFmt<WD>::kColMask));
+      v[i] = vs_lds_f64(kVsDictOff + ((f[i] >> VsFmt<WD>::kDictShift) & VsFmt<WD>::kDictMask));
     }
     // keep the eight gathers of the chunk ahead of the (masked) fmas
 #pragma unroll
@@ -97,7 +111,7 @@ __device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem
 // entry, window columns differing by one constant per row) -- the rows of one node type inside a mesh
 // brick.  One row is stored (a dword per lane and chunk, lane-major), the others add their window shift
 // sh[i] (bytes): 1/R of the stream, one dictionary gather instead of R.
-template <int NCH, int R>
+template <int NCH, int R, int WD>
 __device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[R], int lane,
                                           const uint8_t *__restrict__ fb, double (&acc)[R]) {
   uint32_t w[NCH];
@@ -106,11 +120,11 @@ __device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[R], i
   w[NCH - 1] = *(const uint32_t *)(fb + 256 * (NCH - 1) + 4 * (lane < rem ? lane : rem - 1));
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
-    const uint32_t lc = w[j] & 0x7ff8u;
-    double v = vs_lds_f64(kVsDictOff + ((w[j] >> 12) & 0xff8u));
+    const uint32_t lc = w[j] & VsFmt<WD>::kColMask;
+    double v = vs_lds_f64(kVsDictOff + ((w[j] >> VsFmt<WD>::kDictShift) & VsFmt<WD>::kDictMask));
     double xv[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) xv[i] = vs_lds_f64(kVsWinOff + (uint32_t)((int32_t)lc + sh[i]));
+    for (int i = 0; i < R; ++i) xv[i] = vs_lds_f64(VsFmt<WD>::kWinOff + (uint32_t)((int32_t)lc + sh[i]));
 #pragma unroll
     for (int i = 0; i < R; ++i) asm volatile("" : "+v"(xv[i]));
     asm volatile("" : "+v"(v));
@@ -127,7 +141,7 @@ __device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[R], i
   }
 }
 
-template <int EPI, int TAG, int NW>
+template <int EPI, int TAG, int NW, int WD = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_vs_kernel(
     const uint8_t *__restrict__ stream, const int64_t *__restrict__ sb, const uint64_t *__restrict__ tab,
     const int32_t *__restrict__ cnt, int32_t stride, const int32_t *__restrict__ blk_seg_begin,
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   extern __shared__ double xs[];
   char *sm = (char *)xs;
   double *ds = (double *)(sm + kVsDictOff);
-  double *xw = (double *)(sm + kVsWinOff);
+  double *xw = (double *)(sm + VsFmt<WD>::kWinOff);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int64_t b = blockIdx.x;
@@ -222,12 +236,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       for (int i = 1; i < 8; ++i) sh[i] = (int32_t)vs_off(desc[i]) - (1 << 19);
       double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       switch (cls) {
-        case 1: vs_shared<1, 8>(rem, sh, lane, fb, acc); break;
-        case 2: vs_shared<2, 8>(rem, sh, lane, fb, acc); break;
-        case 3: vs_shared<3, 8>(rem, sh, lane, fb, acc); break;
-        case 4: vs_shared<4, 8>(rem, sh, lane, fb, acc); break;
-        case 5: vs_shared<5, 8>(rem, sh, lane, fb, acc); break;
-        default: vs_shared<6, 8>(rem, sh, lane, fb, acc); break;
+        case 1: vs_shared<1, 8, WD>(rem, sh, lane, fb, acc); break;
+        case 2: vs_shared<2, 8, WD>(rem, sh, lane, fb, acc); break;
+        case 3: vs_shared<3, 8, WD>(rem, sh, lane, fb, acc); break;
+        case 4: vs_shared<4, 8, WD>(rem, sh, lane, fb, acc); break;
+        case 5: vs_shared<5, 8, WD>(rem, sh, lane, fb, acc); break;
+        default: vs_shared<6, 8, WD>(rem, sh, lane, fb, acc); break;
       }
       const double s8 = reduce_rows8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], lane);
       // lane 16 q + 8 h (q = 0..3, h = 0..1) holds the tree of batch row {0, 2, 1, 3}[q] + 4 h
@@ -257,12 +271,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
       const int32_t sh[4] = {0, (int32_t)vs_off(desc[1]) - (1 << 19), (int32_t)vs_off(desc[2]) - (1 << 19),
                              (int32_t)vs_off(desc[3]) - (1 << 19)};
       switch (cls) {
-        case 1: vs_shared<1, 4>(rem, sh, lane, fb, acc); break;
-        case 2: vs_shared<2, 4>(rem, sh, lane, fb, acc); break;
-        case 3: vs_shared<3, 4>(rem, sh, lane, fb, acc); break;
-        case 4: vs_shared<4, 4>(rem, sh, lane, fb, acc); break;
-        case 5: vs_shared<5, 4>(rem, sh, lane, fb, acc); break;
-        default: vs_shared<6, 4>(rem, sh, lane, fb, acc); break;
+        case 1: vs_shared<1, 4, WD>(rem, sh, lane, fb, acc); break;
+        case 2: vs_shared<2, 4, WD>(rem, sh, lane, fb, acc); break;
+        case 3: vs_shared<3, 4, WD>(rem, sh, lane, fb, acc); break;
+        case 4: vs_shared<4, 4, WD>(rem, sh, lane, fb, acc); break;
+        case 5: vs_shared<5, 4, WD>(rem, sh, lane, fb, acc); break;
+        default: vs_shared<6, 4, WD>(rem, sh, lane, fb, acc); break;
       }
     } else {
       int32_t rem[4], maxrem = 1;
@@ -272,12 +286,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         maxrem = rem[i] > maxrem ? rem[i] : maxrem;
       }
       switch (cls) {
-        case 1: vs_batch<1>(rem, maxrem, lane, fb, sm, acc); break;
-        case 2: vs_batch<2>(rem, maxrem, lane, fb, sm, acc); break;
-        case 3: vs_batch<3>(rem, maxrem, lane, fb, sm, acc); break;
-        case 4: vs_batch<4>(rem, maxrem, lane, fb, sm, acc); break;
-        case 5: vs_batch<5>(rem, maxrem, lane, fb, sm, acc); break;
-        case 6: vs_batch<6>(rem, maxrem, lane, fb, sm, acc); break;
+        case 1: vs_batch<1, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 2: vs_batch<2, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 3: vs_batch<3, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 4: vs_batch<4, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 5: vs_batch<5, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 6: vs_batch<6, WD>(rem, maxrem, lane, fb, sm, acc); break;
         default: break;  // class 0: empty rows
       }
     }

@@ -236,6 +236,7 @@ struct Params {
   // also emit G_ij = int_Gamma phi_i phi_j on the background space (the particle-assembled
   // AL term of the "operator form", immersed_laplace.cc:659-705)
   int want_surface_mass = 0;
+  int assembly = 0;  // 1: cell-wise sums of one numerically integrated cell matrix in Morton order (synth.h)
   // linear elasticity (BASELINE cfg 5): background Lame parameters; lame2_* = the JUMP
   // (immersed minus background) that A2 carries, as beta_2 - beta_1 does in the scalar case
   // (elliptic_interface.cc:648-663).  immersed_kind 2: 3-D box [box_lo, box_hi] meshed with
@@ -278,6 +279,72 @@ struct Grid {
   }
 };
 
+// ---- cell-wise assembly (Params::assembly == 1) ------------------------------------------------
+// The local matrix of ONE cell, integrated as an FE library does: tensor Gauss quadrature with p + 2 points per
+// direction, Jacobian (diagonal) from the vertex coordinates of cell 0, shape gradients J^-T grad_hat, the
+// quadrature sum accumulated point by point.  Index: ((local node) * nc + a) x ((local node) * nc + b),
+// local node = (l2 * (p+1) + l1) * (p+1) + l0.
+struct CellMatrix {
+  int nl, nc;
+  std::vector<double> k;
+  double at(int li, int a, int lj, int b) const { return k[((size_t)li * nc + a) * (nl * nc) + (size_t)lj * nc + b]; }
+};
+CellMatrix cell_matrix(const Params &P, const Grid &g) {
+  const int dim = g.dim, p = g.p, n1l = p + 1, nc = P.ncomp;
+  CellMatrix C;
+  C.nl = dim == 3 ? n1l * n1l * n1l : n1l * n1l;
+  C.nc = nc;
+  C.k.assign((size_t)C.nl * nc * C.nl * nc, 0.0);
+  // vertex coordinates of cell 0 along each axis -> Jacobian entries (as a mapping would compute them)
+  const double x0 = g.lo, x1 = g.lo + g.h;
+  const double jac = x1 - x0, jinv = 1.0 / jac;
+  Gauss q(p + 2);
+  const int nq = (int)q.x.size();
+  const double ggd = (P.stokes && P.grad_div) ? P.gamma_grad_div : 0.0;
+  std::vector<double> grad((size_t)C.nl * 3);
+  double v[3][3], d[3][3];
+  for (int q2 = 0; q2 < (dim == 3 ? nq : 1); ++q2)
+    for (int q1 = 0; q1 < nq; ++q1)
+      for (int q0 = 0; q0 < nq; ++q0) {
+        shape1d(p, q.x[q0], v[0], d[0]);
+        shape1d(p, q.x[q1], v[1], d[1]);
+        if (dim == 3) shape1d(p, q.x[q2], v[2], d[2]);
+        double jxw = q.w[q0] * q.w[q1] * (dim == 3 ? q.w[q2] : 1.0);
+        for (int a = 0; a < dim; ++a) jxw *= jac;
+        for (int l = 0; l < C.nl; ++l) {
+          const int l0 = l % n1l, l1 = (l / n1l) % n1l, l2 = l / (n1l * n1l);
+          const double s0 = v[0][l0], s1 = v[1][l1], s2 = dim == 3 ? v[2][l2] : 1.0;
+          grad[l * 3 + 0] = jinv * (d[0][l0] * s1 * s2);
+          grad[l * 3 + 1] = jinv * (s0 * d[1][l1] * s2);
+          grad[l * 3 + 2] = dim == 3 ? jinv * (s0 * s1 * d[2][l2]) : 0.0;
+        }
+        for (int li = 0; li < C.nl; ++li)
+          for (int lj = 0; lj < C.nl; ++lj) {
+            double gg = 0.0;
+            for (int a = 0; a < dim; ++a) gg += grad[li * 3 + a] * grad[lj * 3 + a];
+            for (int a = 0; a < nc; ++a)
+              for (int b = 0; b < nc; ++b) {
+                double e = (a == b) ? P.beta * gg : 0.0;
+                if (nc > 1 && ggd != 0.0) e += ggd * (grad[li * 3 + a] * grad[lj * 3 + b]);   // (div u, div v)
+                C.k[((size_t)li * nc + a) * (C.nl * nc) + (size_t)lj * nc + b] += e * jxw;
+              }
+          }
+      }
+  return C;
+}
+inline uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+  auto spread = [](uint64_t v) {
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+  };
+  return spread(x) | spread(y) << 1 | spread(z) << 2;
+}
+
 // Velocity / background block. For ncomp == 1: beta * stiffness. For
 // ncomp == dim: vector Laplace (+ gamma_gd * grad-div).
 void build_A(const Params &P, const Grid &g, Csr &A, int64_t node0, int64_t node1) {
@@ -317,6 +384,9 @@ void build_A(const Params &P, const Grid &g, Csr &A, int64_t node0, int64_t node
   A.col.resize(A.row_ptr[nrows]);
   A.val.resize(A.row_ptr[nrows]);
   const double ggd = (P.stokes && P.grad_div) ? P.gamma_grad_div : 0.0;
+  const bool cellwise = P.assembly == 1 && !P.elasticity;
+  CellMatrix KC;
+  if (cellwise) KC = cell_matrix(P, g);
   // pass 2: fill
 #pragma omp parallel for schedule(static)
   for (int64_t n = node0; n < node1; ++n) {
@@ -343,6 +413,49 @@ void build_A(const Params &P, const Grid &g, Csr &A, int64_t node0, int64_t node
           j[1] = f1 + k1;
           j[2] = f2 + k2;
           if (g.boundary(j)) continue;
+          if (cellwise) {
+            // cells holding both nodes, visited in Morton order; global entry = running sum of their contributions
+            int clo[3] = {0, 0, 0}, chi[3] = {0, 0, 0};
+            for (int a = 0; a < dim; ++a) {
+              const int ilo = idx[a] % g.p == 0 ? std::max(0, idx[a] / g.p - 1) : idx[a] / g.p;
+              const int ihi = idx[a] % g.p == 0 ? std::min(g.N - 1, idx[a] / g.p) : idx[a] / g.p;
+              const int jlo = j[a] % g.p == 0 ? std::max(0, j[a] / g.p - 1) : j[a] / g.p;
+              const int jhi = j[a] % g.p == 0 ? std::min(g.N - 1, j[a] / g.p) : j[a] / g.p;
+              clo[a] = std::max(ilo, jlo);
+              chi[a] = std::min(ihi, jhi);
+            }
+            struct CellRef {
+              uint64_t key;
+              int c[3];
+            } cells[8];
+            int ncell = 0;
+            for (int c2 = clo[2]; c2 <= chi[2]; ++c2)
+              for (int c1 = clo[1]; c1 <= chi[1]; ++c1)
+                for (int c0 = clo[0]; c0 <= chi[0]; ++c0) {
+                  cells[ncell].key = morton3((uint32_t)c0, (uint32_t)c1, (uint32_t)c2);
+                  cells[ncell].c[0] = c0, cells[ncell].c[1] = c1, cells[ncell].c[2] = c2;
+                  ++ncell;
+                }
+            std::sort(cells, cells + ncell, [](const CellRef &x, const CellRef &y) { return x.key < y.key; });
+            const int64_t jn = g.node(j);
+            const int n1l = g.p + 1;
+            double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int ci = 0; ci < ncell; ++ci) {
+              int li = 0, lj = 0;
+              for (int a = dim - 1; a >= 0; --a) {
+                li = li * n1l + (idx[a] - cells[ci].c[a] * g.p);
+                lj = lj * n1l + (j[a] - cells[ci].c[a] * g.p);
+              }
+              for (int a = 0; a < nc; ++a)
+                for (int b = 0; b < nc; ++b) acc[a][b] += KC.at(li, a, lj, b);
+            }
+            for (int a = 0; a < nc; ++a)
+              for (int b = 0; b < nc; ++b) {
+                A.col[pos[a]] = (int32_t)(jn * nc + b);
+                A.val[pos[a]++] = acc[a][b];
+              }
+            continue;
+          }
           // per axis: M, K, G[i][j], G[j][i]
           double m[3] = {1, 1, 1}, k[3] = {0, 0, 0}, gij[3] = {0, 0, 0}, gji[3] = {0, 0, 0};
           for (int a = 0; a < dim; ++a) {
@@ -1138,6 +1251,7 @@ void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
   P.imm_hi = sp->imm_hi;
   P.beta2 = sp->beta2;
   P.want_surface_mass = sp->want_surface_mass;
+  P.assembly = sp->assembly;
   P.elasticity = sp->elasticity;
   P.lame_lambda = sp->lame_lambda;
   P.lame_mu = sp->lame_mu;
@@ -1157,6 +1271,68 @@ void *alfd_synth_generate(const alfd_synth_params *sp, char *err, int errlen) {
 }
 
 void alfd_synth_free(void *h) { delete static_cast<Problem *>(h); }
+
+int alfd_synth_permute_nodes(void *h, const int64_t *new_to_old, int64_t n_nodes) {
+  Problem *pb = static_cast<Problem *>(h);
+  const Params &P = pb->p;
+  if (P.u_node0 >= 0) return -1;                       // unpartitioned problems only
+  auto itA = pb->mats.find("A");
+  if (itA == pb->mats.end()) return -1;
+  const int nc = P.ncomp;
+  if (itA->second.nrows != n_nodes * nc) return -1;
+  const int64_t n = n_nodes * nc;
+  std::vector<int64_t> old_to_new_node(n_nodes, -1);
+  for (int64_t k = 0; k < n_nodes; ++k) {
+    if (new_to_old[k] < 0 || new_to_old[k] >= n_nodes || old_to_new_node[new_to_old[k]] >= 0) return -2;
+    old_to_new_node[new_to_old[k]] = k;
+  }
+  auto new_of = [&](int64_t dof) { return old_to_new_node[dof / nc] * nc + dof % nc; };
+  auto old_of = [&](int64_t dof) { return new_to_old[dof / nc] * nc + dof % nc; };
+  // rows: out row r = in row old_of(r); cols mapped (and re-sorted) when map_cols
+  auto permute = [&](Csr &m, bool map_rows, bool map_cols) {
+    Csr o;
+    o.nrows = m.nrows;
+    o.ncols = m.ncols;
+    o.row_ptr.assign(m.nrows + 1, 0);
+    for (int64_t r = 0; r < m.nrows; ++r) {
+      const int64_t src = map_rows ? old_of(r) : r;
+      o.row_ptr[r + 1] = m.row_ptr[src + 1] - m.row_ptr[src];
+    }
+    for (int64_t r = 0; r < m.nrows; ++r) o.row_ptr[r + 1] += o.row_ptr[r];
+    o.col.resize(m.nnz());
+    o.val.resize(m.nnz());
+#pragma omp parallel
+    {
+      std::vector<std::pair<int32_t, double>> row;
+#pragma omp for schedule(static)
+      for (int64_t r = 0; r < m.nrows; ++r) {
+        const int64_t src = map_rows ? old_of(r) : r;
+        const int64_t k0 = m.row_ptr[src], len = m.row_ptr[src + 1] - k0, o0 = o.row_ptr[r];
+        if (!map_cols) {
+          for (int64_t k = 0; k < len; ++k) o.col[o0 + k] = m.col[k0 + k], o.val[o0 + k] = m.val[k0 + k];
+          continue;
+        }
+        row.resize(len);
+        for (int64_t k = 0; k < len; ++k) row[k] = {(int32_t)new_of(m.col[k0 + k]), m.val[k0 + k]};
+        std::sort(row.begin(), row.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        for (int64_t k = 0; k < len; ++k) o.col[o0 + k] = row[k].first, o.val[o0 + k] = row[k].second;
+      }
+    }
+    m = std::move(o);
+  };
+  permute(itA->second, true, true);
+  for (const char *name : {"Bt", "Ct"})
+    if (pb->mats.count(name)) permute(pb->mats[name], true, false);
+  for (const char *name : {"B", "C"})
+    if (pb->mats.count(name)) permute(pb->mats[name], false, true);
+  if (pb->mats.count("G")) permute(pb->mats["G"], true, true);
+  if (pb->vecs.count("f") && (int64_t)pb->vecs["f"].size() == n) {
+    std::vector<double> f(n);
+    for (int64_t r = 0; r < n; ++r) f[r] = pb->vecs["f"][old_of(r)];
+    pb->vecs["f"] = f;
+  }
+  return 0;
+}
 
 // Returns 0 and fills dims/pointers if the matrix exists, else -1. Pointers
 // stay valid until alfd_synth_free.

@@ -34,7 +34,7 @@ class _Params(C.Structure):
         ("l0", C.c_int64), ("l1", C.c_int64),
         ("immersed_kind", C.c_int32), ("imm_cells", C.c_int32),
         ("imm_lo", C.c_double), ("imm_hi", C.c_double), ("beta2", C.c_double),
-        ("want_surface_mass", C.c_int32), ("pad_", C.c_int32),
+        ("want_surface_mass", C.c_int32), ("assembly", C.c_int32),
         ("elasticity", C.c_int32), ("pad2_", C.c_int32),
         ("lame_lambda", C.c_double), ("lame_mu", C.c_double),
         ("lame2_lambda", C.c_double), ("lame2_mu", C.c_double),
@@ -61,6 +61,8 @@ def _load():
         lib.alfd_synth_vector.restype = C.c_int
         lib.alfd_synth_vector.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64),
                                           C.POINTER(C.POINTER(C.c_double))]
+        lib.alfd_synth_permute_nodes.restype = C.c_int
+        lib.alfd_synth_permute_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         lib.alfd_synth_transpose.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
@@ -198,7 +200,7 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
              gamma_grad_div=0.0, beta=1.0, center=(0.5, 0.5, 0.5), radius=0.2, immersed_refine=3,
              coupling_nq=3, body_force=(0.0, 0.0, 0.0), embedded_value=(1.0, 0.0, 0.0),
              row_ranges=None, immersed_box=None, beta2=0.0, surface_mass=False,
-             elasticity=None, immersed_box3d=None, immersed_segments=0) -> SyntheticProblem:
+             elasticity=None, immersed_box3d=None, immersed_segments=0, assembly="kronecker") -> SyntheticProblem:
     """immersed_box = (lo, hi, cells): the immersed domain is the 2-D box [lo,hi]^2
     with cells^2 Q1 cells (volume coupling, elliptic_interface); beta2 scales "A2".
     elasticity = (lambda, mu, lambda_jump, mu_jump): vector-Q1 linear elasticity on the background
@@ -221,6 +223,7 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
     rr = tuple(int(v) for v in row_ranges) if row_ranges is not None else (-1,) * 6
     p.u_node0, p.u_node1, p.p_node0, p.p_node1, p.l0, p.l1 = rr
     p.want_surface_mass = int(surface_mass)
+    p.assembly = {"kronecker": 0, "cellwise": 1}[assembly]
     if immersed_box is not None:
         p.immersed_kind, p.imm_lo, p.imm_hi, p.imm_cells = 1, float(immersed_box[0]), float(immersed_box[1]), int(immersed_box[2])
         p.beta2 = beta2
@@ -241,10 +244,18 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
         raise ValueError("synthetic generator: " + err.value.decode())
     params = dict(dim=dim, degree=degree, ncomp=ncomp, n_cells=n_cells, lo=lo, hi=hi, stokes=stokes,
                   grad_div=grad_div, gamma_grad_div=gamma_grad_div, beta=beta, center=tuple(center),
-                  radius=radius, immersed_refine=immersed_refine, coupling_nq=coupling_nq)
+                  radius=radius, immersed_refine=immersed_refine, coupling_nq=coupling_nq, assembly=assembly)
     owner = _NativeHandle(h)
     pb = SyntheticProblem(params=params, _handle=owner,
                           row_ranges=rr if row_ranges is not None else None)
+    _fetch_views(pb)
+    return pb
+
+
+def _fetch_views(pb: "SyntheticProblem"):
+    """(Re)binds pb.mats / pb.vecs to the native arrays of pb._handle."""
+    lib, owner = _load(), pb._handle
+    pb.mats, pb.vecs = {}, {}
     for name in ("A", "B", "Bt", "Mp", "Ct", "C", "M", "K", "A2", "G"):
         nr, nc, nnz = C.c_int64(), C.c_int64(), C.c_int64()
         rp, col, val = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()
@@ -259,6 +270,20 @@ def generate(dim=2, degree=1, ncomp=1, n_cells=16, lo=0.0, hi=1.0, stokes=False,
         if lib.alfd_synth_vector(owner.ptr, name.encode(), C.byref(n), C.byref(data)) != 0:
             continue
         pb.vecs[name] = _view(data, n.value, C.c_double, np.float64, owner)
+
+
+def permute_background_nodes(pb: "SyntheticProblem", new_to_old) -> "SyntheticProblem":
+    """Renumber the nodes of the background / velocity space IN PLACE (alfd_synth_permute_nodes): node new_to_old[k]
+    becomes node k -- what a caller's DoF renumbering (DoFRenumbering::Cuthill_McKee, then component-wise blocks,
+    stokes_immersed_boundary.cc:533-541) does to A, Bt / B, Ct / C and f.  pb.node_permutation records new_to_old
+    (composed with an earlier one), so that support points and tensor-grid helpers can follow."""
+    perm = np.ascontiguousarray(new_to_old, np.int64)
+    rc = _load().alfd_synth_permute_nodes(pb._handle.ptr, perm.ctypes.data, perm.size)
+    if rc != 0:
+        raise ValueError(f"alfd_synth_permute_nodes failed ({rc})")
+    prev = getattr(pb, "node_permutation", None)
+    _fetch_views(pb)
+    pb.node_permutation = perm if prev is None else prev[perm]
     return pb
 
 
@@ -294,7 +319,7 @@ def laplace3d_sphere(n_cells=128, immersed_refine=5, coupling_nq=3) -> Synthetic
 
 
 def stokes3d_sphere(n_cells=64, immersed_refine=4, gamma_grad_div=10.0, coupling_nq=4,
-                    row_ranges=None) -> SyntheticProblem:
+                    row_ranges=None, assembly="kronecker") -> SyntheticProblem:
     """cfg 4 (north star): stokes_immersed_boundary + parameters_stokes_3d.prm.
     Taylor-Hood Q2/Q1 on n^3 cells, grad-div on (prm:21), sphere R = 0.1 centre
     (.5,.5,.5) (stokes_immersed_boundary.cc:427), body force (1,0,0) (prm:52),
@@ -302,7 +327,8 @@ def stokes3d_sphere(n_cells=64, immersed_refine=4, gamma_grad_div=10.0, coupling
     return generate(dim=3, degree=2, ncomp=3, n_cells=n_cells, stokes=True, grad_div=True,
                     gamma_grad_div=gamma_grad_div, center=(0.5, 0.5, 0.5), radius=0.1,
                     immersed_refine=immersed_refine, coupling_nq=coupling_nq,
-                    body_force=(1.0, 0.0, 0.0), embedded_value=(-1.0, 1.0, 0.0), row_ranges=row_ranges)
+                    body_force=(1.0, 0.0, 0.0), embedded_value=(-1.0, 1.0, 0.0), row_ranges=row_ranges,
+                    assembly=assembly)
 
 
 def stokes2d_circle(n_cells=32, immersed_refine=4, gamma_grad_div=10.0, coupling_nq=3) -> SyntheticProblem:
@@ -349,14 +375,36 @@ def elasticity3d(n_bg=16, cells_fg=None, lame_bg=(2.0, 1.0), lame_fg=(20.0, 10.0
                     immersed_box3d=(box[0], box[1], cells_fg), row_ranges=row_ranges)
 
 
-def row_support_points(params: dict, node_range=None):
+def cuthill_mckee_nodes(pb: "SyntheticProblem"):
+    """new_to_old node permutation of the background space in Cuthill-McKee order of the node graph of A (what
+    DoFRenumbering::Cuthill_McKee produces before the component-wise block sort of stokes_immersed_boundary.cc:
+    533-541 moves the velocity block in front: inside that block the nodes keep this order).  SciPy's routine
+    returns the REVERSE ordering; deal.II's default is the plain one."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    A, nc = pb.mats["A"], pb.params["ncomp"]
+    rows0 = np.arange(0, A.nrows, nc)
+    starts = A.row_ptr[rows0]
+    lens = A.row_ptr[rows0 + 1] - starts
+    idx = np.repeat(starts, lens) + (np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens))
+    cols = A.col[idx]
+    keep = cols % nc == 0
+    g = sp.csr_matrix((np.ones(int(keep.sum()), np.int8), (np.repeat(np.arange(rows0.size), lens)[keep], cols[keep] // nc)),
+                      shape=(rows0.size, rows0.size))
+    return np.ascontiguousarray(reverse_cuthill_mckee(g, symmetric_mode=True)[::-1]).astype(np.int64)
+
+
+def row_support_points(params: dict, node_range=None, node_permutation=None):
     """One support point per row of the block-(0,0) operator of a tensor-grid problem (node-major
     numbering: the ncomp rows of a node share its point) -- what DoFTools::map_dofs_to_support_points
-    gives a deal.II caller; input of solver.row_blocks_from_points."""
+    gives a deal.II caller; input of solver.row_blocks_from_points.  node_permutation: the new_to_old node
+    renumbering the problem carries (SyntheticProblem.node_permutation)."""
     dim, ncomp = params["dim"], params["ncomp"]
     n1 = params["degree"] * params["n_cells"] + 1
     n0, n_end = (0, n1 ** dim) if node_range is None else (int(node_range[0]), int(node_range[1]))
     idx = np.arange(n0, n_end, dtype=np.int64)
+    if node_permutation is not None:
+        idx = np.asarray(node_permutation, np.int64)
     h = (params["hi"] - params["lo"]) / (n1 - 1)
     pts = np.stack([params["lo"] + h * ((idx // n1 ** d) % n1) for d in range(dim)], axis=1)
     return np.repeat(pts, ncomp, axis=0)
@@ -449,7 +497,7 @@ def _interp1d(n_fine_cells: int, n_coarse_cells: int):
     return np.asarray(rows), np.asarray(cols), np.asarray(vals)
 
 
-def tensor_prolongators(params: dict, min_coarse: int = 400, max_levels: int = 7):
+def tensor_prolongators(params: dict, min_coarse: int = 400, max_levels: int = 7, node_permutation=None):
     """Geometric multigrid transfers of the tensor-grid background space, as CSR prolongators for
     Context.set_prolongator (alfd_set_prolongator): level 0 embeds the Q1 space of the SAME mesh into the
     nodal grid of the degree-p space (for Q2 that is linear interpolation from n to 2n cells -- the Q1
@@ -457,7 +505,8 @@ def tensor_prolongators(params: dict, min_coarse: int = 400, max_levels: int = 7
     of ceil(n/2) cells (nested when n is even).  All components of a node interpolate alike; Dirichlet
     (boundary) nodes are neither interpolated to nor from, coarse unknowns are the INTERIOR nodes of the
     coarse grid in lexicographic order, node-major.  What a deal.II caller takes from MGTransferPrebuilt /
-    FETools::get_interpolation_matrix.  Returns [(Csr P, n_coarse), ...]."""
+    FETools::get_interpolation_matrix.  node_permutation: new_to_old node renumbering of the fine space
+    (SyntheticProblem.node_permutation).  Returns [(Csr P, n_coarse), ...]."""
     import scipy.sparse as sp
     dim, ncomp, degree = params["dim"], params["ncomp"], params["degree"]
     nf = degree * params["n_cells"]               # cells of the fine nodal grid
@@ -480,6 +529,9 @@ def tensor_prolongators(params: dict, min_coarse: int = 400, max_levels: int = 7
         pv.eliminate_zeros()
         pv.sort_indices()
         n_coarse = int(pv.shape[1])
+        if not levels and node_permutation is not None:        # level-0 rows follow the problem's node numbering
+            perm = np.asarray(node_permutation, np.int64)
+            pv = pv[(perm[:, None] * ncomp + np.arange(ncomp)[None, :]).ravel(), :]
         levels.append((Csr.from_scipy(pv), n_coarse))
         if n_coarse <= min_coarse:
             break

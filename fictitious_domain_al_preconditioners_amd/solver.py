@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "alfd_host_aggregate_level", "alfd_comm_init_host",
     "alfd_get_device_memory", "alfd_set_row_blocks", "alfd_host_stream_plan",
     "alfd_host_row_blocks_from_points", "alfd_host_stream_plan_short", "alfd_set_prolongator", "alfd_set_controls", "alfd_get_timing_streamed", "alfd_get_setup_seconds",
+    "alfd_host_numbering_from_points", "alfd_host_brick_blocks_from_points", "alfd_host_permute_csr",
 ]
 
 
@@ -111,6 +112,9 @@ def load_library():
         "alfd_host_stream_plan": (C.c_int, [i64, vp, vp, vp, C.c_int32, i64, vp, vp, vp]),
         "alfd_host_row_blocks_from_points": (C.c_int, [i64, C.c_int32, vp, C.c_int32, vp, vp, vp]),
         "alfd_host_stream_plan_short": (C.c_int, [i64, vp, vp, vp, C.c_int32, vp]),
+        "alfd_host_numbering_from_points": (C.c_int, [i64, C.c_int32, vp, vp]),
+        "alfd_host_brick_blocks_from_points": (C.c_int, [i64, C.c_int32, vp, vp, C.c_int32, vp, vp, vp]),
+        "alfd_host_permute_csr": (C.c_int, [i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -453,6 +457,50 @@ def host_stream_plan_short(m, lanes):
     if rc != _abi.OK:
         raise AlfdError(rc, "alfd_host_stream_plan_short failed")
     return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+def numbering_from_points(points):
+    """new_to_old permutation that puts unknowns into the lexicographic order of their support points
+    (alfd_host_numbering_from_points); the components of a node stay together."""
+    pts = np.ascontiguousarray(points, np.float64)
+    out = np.empty(pts.shape[0], np.int64)
+    rc = load_library().alfd_host_numbering_from_points(pts.shape[0], pts.shape[1], pts.ctypes.data, out.ctypes.data)
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_numbering_from_points")
+    return out
+
+
+def brick_blocks_from_points(points, brick=(16, 4, 1), max_rows=250):
+    """(block_ptr, rows) for Context.set_row_blocks: mesh bricks found from support points alone
+    (alfd_host_brick_blocks_from_points)."""
+    pts = np.ascontiguousarray(points, np.float64)
+    n, dim = pts.shape
+    b = np.ascontiguousarray(list(brick)[:dim], np.int32)
+    bp = np.empty(n + 1, np.int64)
+    rows = np.empty(n, np.int32)
+    nb = C.c_int64(0)
+    rc = load_library().alfd_host_brick_blocks_from_points(n, dim, pts.ctypes.data, b.ctypes.data, max_rows, C.byref(nb),
+                                                           bp.ctypes.data, rows.ctypes.data)
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_brick_blocks_from_points")
+    return bp[:nb.value + 1].copy(), rows
+
+
+def permute_csr(m, row_new_to_old=None, col_old_to_new=None):
+    """problems.Csr permuted on the host (alfd_host_permute_csr): rows taken in the order row_new_to_old, column j
+    renamed col_old_to_new[j], rows re-sorted."""
+    from .problems import Csr
+    rp = np.empty(m.nrows + 1, np.int64)
+    col = np.empty(m.nnz, np.int32)
+    val = np.empty(m.nnz, np.float64)
+    r = None if row_new_to_old is None else np.ascontiguousarray(row_new_to_old, np.int64)
+    c = None if col_old_to_new is None else np.ascontiguousarray(col_old_to_new, np.int64)
+    rc = load_library().alfd_host_permute_csr(m.nrows, m.row_ptr.ctypes.data, m.col.ctypes.data, m.val.ctypes.data,
+                                              None if r is None else r.ctypes.data, None if c is None else c.ctypes.data,
+                                              rp.ctypes.data, col.ctypes.data, val.ctypes.data)
+    if rc != _abi.OK:
+        raise AlfdError(rc, "alfd_host_permute_csr")
+    return Csr(m.nrows, m.ncols, rp, col, val)
 
 
 def row_blocks_from_points(points, max_rows=192):

@@ -396,6 +396,9 @@ typedef struct alfd_matrix_info {
   int64_t nnz, window_blocks, window_fallback_blocks;
   int64_t value_indexed_blocks, value_indexed_nnz, dictionary_entries, value_wide_nnz;
   double algorithmic_bytes, streamed_bytes;
+  int64_t shared_nnz;    /* batch-major forms: entries of rows stored as translates of a template row */
+  int64_t batch_major_blocks;
+  int64_t batch_major_wide;  /* 1: 10-bit dictionary codes / 11-bit window columns (blocks with > 512 distinct values) */
 } alfd_matrix_info;
 int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out);
 /* Host-only (no device, no context): plans the LDS-window / value-indexed storage of
@@ -450,6 +453,28 @@ int alfd_set_row_blocks(alfd_ctx_t ctx, int slot, int64_t n_blocks, const int64_
 int alfd_host_row_blocks_from_points(int64_t nrows, int32_t dim, const double *points, int32_t max_rows,
                                      int64_t *n_blocks_out, int64_t *block_ptr_out, int32_t *rows_out);
 
+/* Host-only helpers for callers whose DoF numbering is not the one the SpMV formats like (a deal.II program numbers
+ * with Cuthill-McKee and then block-wise, stokes_immersed_boundary.cc:533-541; the batch-major form wants the rows of a
+ * mesh brick to read a compact set of columns).  From one support point per unknown of a block
+ * (DoFTools::map_dofs_to_support_points):
+ *   alfd_host_numbering_from_points: new_to_old[nrows] = the unknowns in lexicographic order of their points (last
+ *     coordinate slowest), unknowns with the same point -- the components of a node -- kept together in their order.
+ *     The front end (include/alfd/dealii_adapter.hpp, solver.py) permutes the operators and vectors with it BEFORE the
+ *     upload and the solution back after the download: results live in the permuted numbering, the library itself
+ *     never sees the caller's one.
+ *   alfd_host_brick_blocks_from_points: row blocks for alfd_set_row_blocks = bricks of brick[0] x brick[1] x brick[2]
+ *     grid nodes, a node's grid index along an axis being the rank of its coordinate among the distinct coordinates
+ *     of that axis (exact on tensor grids, consistent on locally refined ones); blocks above max_rows rows are split.
+ *   alfd_host_permute_csr: out = in with rows taken in the order row_new_to_old (NULL: unchanged) and column j renamed
+ *     col_old_to_new[j] (NULL: unchanged), the entries of a row re-sorted by the new column.  out_row_ptr[nrows + 1],
+ *     out_col / out_val [nnz]. */
+int alfd_host_numbering_from_points(int64_t nrows, int32_t dim, const double *points, int64_t *new_to_old);
+int alfd_host_brick_blocks_from_points(int64_t nrows, int32_t dim, const double *points, const int32_t *brick,
+                                       int32_t max_rows, int64_t *n_blocks_out, int64_t *block_ptr_out, int32_t *rows_out);
+int alfd_host_permute_csr(int64_t nrows, const int64_t *row_ptr, const int32_t *col, const double *val,
+                          const int64_t *row_new_to_old, const int64_t *col_old_to_new, int64_t *out_row_ptr,
+                          int32_t *out_col, double *out_val);
+
 /* Free / total bytes of the context's device (hipMemGetInfo): leak checks, capacity planning. */
 int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_bytes);
 /* Run-time switches of a context (measurement and A/B comparison; results never change):
@@ -463,7 +488,9 @@ int alfd_get_device_memory(alfd_ctx_t ctx, int64_t *free_bytes, int64_t *total_b
  *                  form when no alfd_set_row_blocks hint is given; "batch_major_waves" (2, 4, 8): waves per workgroup;
  *                  "batch_major_xcd" (0/1): XCD-contiguous block order (measured slower); "batch_major_share" (0/1):
  *                  store rows that are translates of one another once (0: every row stored, ~3.1 B/nnz -- what a
- *                  matrix with repeating values but no translate structure gets; at the next alfd_set_matrix).
+ *                  matrix with repeating values but no translate structure gets; at the next alfd_set_matrix);
+ *                  "batch_major_wide" (0/1, default 1): blocks with more than 512 distinct values are re-planned with
+ *                  10-bit codes / 11-bit window columns instead of being halved (cell-wise assembled matrices).
  * Returns ALFD_E_INVALID for an unknown name. */
 int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value);
 /* Kernel-class timing of the last solve, accumulated with HIP events when

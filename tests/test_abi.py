@@ -46,7 +46,7 @@ def test_version_strerror_and_default_config_mirror():
     assert (c.restart, c.inner.max_steps, c.inner.tol, c.inner.kind) == (30, 100, 1e-2, _abi.CTRL_ABS)
     assert _abi.default_config(_abi.AL_ELL_MODIFIED).restart == 50
     assert C.sizeof(_abi.Config) == 264 and C.sizeof(_abi.Result) == 80
-    assert C.sizeof(_abi.MatrixInfo) == 88 and C.sizeof(_abi.WindowPlanInfo) == 88
+    assert C.sizeof(_abi.MatrixInfo) == 112 and C.sizeof(_abi.WindowPlanInfo) == 88
 
 
 def test_argument_validation_without_gpu():
@@ -104,12 +104,18 @@ def test_host_stream_plan_decodes_back():
     ptr = ptr[ptr <= a.nrows]
     ragged = solver.host_stream_plan(a, blocks=(ptr, perm))
     assert ragged["ok"] and ragged["decode_mismatches"] == 0 and ragged["rows_covered"] == a.nrows
-    # every value scaled by one of 16 factors: blocks exceed the 512 dictionary entries and are halved
+    # every value scaled by one of 16 factors: some blocks exceed 512 distinct values (with 9-bit codes alone they were
+    # halved) -- re-planned with 10-bit codes / 11-bit window columns (VsFmt<1>: up to 1024 values per block), none is cut
     v = np.array(a.val) * (1.0 + 0.0625 * rng.integers(0, 16, a.nnz))
+    wide = solver.host_stream_plan(problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), v))
+    assert wide["ok"] and wide["decode_mismatches"] == 0 and wide["rows_covered"] == a.nrows
+    assert wide["blocks"] == runs["blocks"] and wide["dictionary_entries"] > 10 * runs["dictionary_entries"]
+    # one of 64 factors: beyond 1024 values per block too, blocks are halved until they fit
+    v = np.array(a.val) * (1.0 + 0.015625 * rng.integers(0, 64, a.nnz))
     many = problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), v)
     info = solver.host_stream_plan(many)
     assert info["ok"] and info["decode_mismatches"] == 0 and info["rows_covered"] == a.nrows
-    assert info["blocks"] > runs["blocks"] and info["dictionary_entries"] <= 512 * info["blocks"]
+    assert info["blocks"] > runs["blocks"] and info["dictionary_entries"] <= 1024 * info["blocks"]
     assert info["shared_nnz"] < runs["shared_nnz"]                       # randomly scaled rows are no translates
     # unrelated values: not representable (the library keeps the other formats)
     rnd = problems.Csr(a.nrows, a.ncols, np.array(a.row_ptr), np.array(a.col), rng.uniform(-1, 1, a.nnz))

@@ -205,3 +205,61 @@ def test_elasticity_operators_against_closed_forms():
     assert abs(C - pb.mats["Ct"].to_scipy().T).max() == 0.0
     assert pb.block_sizes == [3 * nn, 3 * 4 * 3 * 3, 3 * 4 * 3 * 3]
     assert np.allclose(pb.vecs["f2"], Mi @ np.ones(Mi.shape[0]))
+
+
+def test_cellwise_assembly_is_the_same_operator_with_other_last_bits():
+    """synth.h `assembly` = 1: one numerically integrated cell matrix, global entries summed in Morton order of the
+    cells (what deal.II's cell loop does): same pattern, symmetric, equal to the Kronecker form up to rounding, and
+    MORE distinct values -- mathematically equal entries differ in their last bits with the order of the cells."""
+    a = problems.stokes3d_sphere(8, 1)
+    b = problems.stokes3d_sphere(8, 1, assembly="cellwise")
+    A, B = a.mats["A"], b.mats["A"]
+    assert np.array_equal(A.row_ptr, B.row_ptr) and np.array_equal(A.col, B.col)
+    assert np.max(np.abs(A.val - B.val)) <= 1e-13 * np.max(np.abs(A.val))
+    S = B.to_scipy()
+    assert abs(S - S.T).max() == 0.0
+    assert np.unique(B.val).size > np.unique(A.val).size
+    for name in ("Bt", "Ct", "Mp"):
+        assert np.array_equal(a.mats[name].val, b.mats[name].val)
+    # scalar Q1 too (immersed_laplace)
+    c = problems.generate(dim=2, degree=1, ncomp=1, n_cells=16, assembly="cellwise")
+    d = problems.generate(dim=2, degree=1, ncomp=1, n_cells=16)
+    assert np.max(np.abs(c.mats["A"].val - d.mats["A"].val)) <= 1e-13
+
+
+def test_node_renumbering_helpers_round_trip():
+    """Cuthill-McKee renumbering of the generated problem, then the front end's numbering from support points
+    (alfd_host_numbering_from_points) brings the lexicographic operators back bit for bit; alfd_host_permute_csr
+    agrees with SciPy; brick blocks from points equal the bricks of the grid."""
+    from fictitious_domain_al_preconditioners_amd import solver
+    pb0 = problems.stokes3d_sphere(6, 0, assembly="cellwise")
+    keep = {k: (m.row_ptr.copy(), m.col.copy(), m.val.copy()) for k, m in pb0.mats.items()}
+    f0 = pb0.vecs["f"].copy()
+    pb = pb0
+    cm = problems.cuthill_mckee_nodes(pb)
+    assert np.array_equal(np.sort(cm), np.arange(cm.size))
+    problems.permute_background_nodes(pb, cm)
+    assert not np.array_equal(pb.mats["A"].col, keep["A"][1])
+    # CM reduces the bandwidth of the node graph below the lexicographic one? not necessarily; it IS a permutation
+    pts = problems.row_support_points(pb.params, node_permutation=pb.node_permutation)
+    n2o = solver.numbering_from_points(pts)
+    assert np.all(n2o.reshape(-1, 3) // 3 == (n2o[::3] // 3)[:, None])
+    problems.permute_background_nodes(pb, n2o[::3] // 3)
+    assert np.array_equal(pb.node_permutation, np.arange(cm.size))
+    for k, (rp, col, val) in keep.items():
+        assert np.array_equal(pb.mats[k].row_ptr, rp) and np.array_equal(pb.mats[k].col, col)
+        assert np.array_equal(pb.mats[k].val, val), k
+    assert np.array_equal(pb.vecs["f"], f0)
+    # permute_csr against SciPy
+    rng = np.random.default_rng(3)
+    A = pb.mats["A"]
+    p = rng.permutation(A.nrows)
+    inv = np.empty_like(p)
+    inv[p] = np.arange(p.size)
+    got = solver.permute_csr(A, row_new_to_old=p, col_old_to_new=inv).to_scipy()
+    ref = A.to_scipy()[p][:, p]
+    assert abs(got - ref).max() == 0.0
+    # bricks from points == bricks from the grid metadata
+    bp, rows = solver.brick_blocks_from_points(problems.row_support_points(pb.params), (4, 4, 1))
+    bp2, rows2 = problems.brick_row_blocks(pb.params, (4, 4, 1))
+    assert np.array_equal(bp, bp2) and np.array_equal(rows, rows2)

@@ -577,6 +577,58 @@ def test_mid_size_solve_with_the_bench_kernels_matches_oracle(built):
         ctx.close()
 
 
+def _reference_shaped(n, refine, numbering, frontend):
+    """Stokes problem with the cell-wise assembled block (0,0) (synth.h `assembly` = 1), optionally renumbered by
+    Cuthill-McKee (stokes_immersed_boundary.cc:533-541) and then by the front end (lexicographic order of the support
+    points); returns (problem, prolongators in that numbering, row blocks)."""
+    pb = problems.stokes3d_sphere(n, refine, assembly="cellwise")
+    if numbering == "cuthill_mckee":
+        problems.permute_background_nodes(pb, problems.cuthill_mckee_nodes(pb))
+    perm = getattr(pb, "node_permutation", None)
+    pts = problems.row_support_points(pb.params, node_permutation=perm)
+    if frontend == "renumber":
+        n2o = solver.numbering_from_points(pts)
+        problems.permute_background_nodes(pb, n2o[::3] // 3)
+        perm = pb.node_permutation
+        pts = problems.row_support_points(pb.params, node_permutation=perm)
+    blocks = solver.brick_blocks_from_points(pts, (16, 4, 1)) if frontend != "none" else None
+    levels = problems.tensor_prolongators(pb.params, min_coarse=_abi.BENCH_MIN_COARSE, node_permutation=perm)
+    return pb, levels, blocks
+
+
+@pytest.mark.parametrize("numbering,frontend", [("lexicographic", "bricks"), ("cuthill_mckee", "none"),
+                                                ("cuthill_mckee", "renumber")])
+def test_reference_shaped_operator_matches_oracle(built, numbering, frontend):
+    """A cell-wise assembled operator (last bits of mathematically equal entries differ with the visiting order of the
+    cells: 720 instead of 285 distinct values) in the numbering a deal.II program hands over, as is and after the front
+    end's renumbering: SpMV bitwise, solve counts and history against the oracle on the SAME arrays, at a size where
+    the window / batch-major kernels run (N = 16: 107 k velocity rows)."""
+    pb, levels, blocks = _reference_shaped(16, 2, numbering, frontend)
+    cfg = _abi.bench_multilevel_settings(_abi.default_config(_abi.AL_STOKES), geometric=True)
+    ctx = solver.context_from_problem(pb, cfg, aggregates=levels, row_blocks=blocks)
+    try:
+        info = ctx.matrix_info(_abi.A)
+        if frontend != "none":       # the fast form, with 10-bit codes because blocks hold > 512 distinct values
+            assert info["batch_major"] == 2 and info["batch_major_wide"] == 1
+            assert info["shared_nnz"] > 0.8 * info["nnz"]
+        x = _rng_vec(pb.block_sizes[0], 7)
+        got, lanes = ctx.spmv(_abi.A, x, np.zeros(pb.block_sizes[0]))
+        ref, _ = oracle.spmv(pb.mats["A"], x, lanes=lanes)
+        assert np.array_equal(got, ref)
+        osys = oracle.system_from_problem(pb, aggregates=levels)
+        rc, rhs = osys.augment_rhs(cfg, cases.rhs_of(pb))
+        assert rc == 0
+        xs, res = ctx.solve(rhs)
+        hist = ctx.history()
+        rc, ox, ores, ohist = osys.solve(cfg, rhs)
+        assert rc == 0 and res.status == 0
+        assert (res.outer_iterations, res.inner_iterations, res.mp_iterations) == \
+               (ores.outer_iterations, ores.inner_iterations, ores.mp_iterations)
+        assert len(hist) == len(ohist) and np.max(np.abs(hist - ohist) / np.abs(ohist)) <= HIST_RTOL
+    finally:
+        ctx.close()
+
+
 def _full_size_properties(pb, cfg, rhs, aggs, outer_band, symmetric, augment, scipy_rows=None, row_blocks=None):
     """Size-independent checks on a full-size BASELINE config (no oracle at this size): linearity of the
     system operator, its symmetry where it is symmetric, the A-SpMV against SciPy, the true residual of
