@@ -81,10 +81,18 @@ class System {
     std::vector<double> val;
     col.reserve(M.n_nonzero_elements());
     val.reserve(M.n_nonzero_elements());
+    // front-end renumbering of the block-0 space (set_numbering_from_support_points): rows of A / BT / CT are taken
+    // in the new order, columns of A / B / C renamed -- the library only ever sees the new numbering
+    const bool prow = !new_to_old_.empty() && (slot == ALFD_A || slot == ALFD_BT || slot == ALFD_CT);
+    const bool pcol = !new_to_old_.empty() && (slot == ALFD_A || slot == ALFD_B || slot == ALFD_C);
+    if ((prow && nrows != (int64_t)new_to_old_.size()) || (pcol && (int64_t)M.n() != (int64_t)new_to_old_.size()))
+      throw Error(ALFD_E_INVALID, "set_matrix: the renumbering does not match this operator's block-0 size");
     std::vector<std::pair<int32_t, double>> row;
     for (int64_t r = 0; r < nrows; ++r) {
       row.clear();
-      for (auto it = M.begin(r); it != M.end(r); ++it) row.emplace_back((int32_t)it->column(), it->value());
+      const int64_t src = prow ? new_to_old_[r] : r;
+      for (auto it = M.begin(src); it != M.end(src); ++it)
+        row.emplace_back(pcol ? (int32_t)old_to_new_[it->column()] : (int32_t)it->column(), it->value());
       std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
       for (const auto &e : row) {
         col.push_back(e.first);
@@ -93,6 +101,66 @@ class System {
       rp[r + 1] = (int64_t)col.size();
     }
     check(alfd_set_matrix(ctx_, slot, nrows, (int64_t)M.n(), rp.data(), col.data(), val.data()));
+  }
+
+  // Front-end renumbering of the block-0 unknowns (velocity / background space) from one support point per unknown
+  // (DoFTools::map_dofs_to_support_points restricted to that block).  The reference numbers its DoFs with
+  // Cuthill-McKee, then block-wise (stokes_immersed_boundary.cc:533-541); the batch-major SpMV wants the rows of a
+  // mesh brick to read a compact window of x.  This call (BEFORE any set_matrix / set_prolongator) fixes a
+  // permutation -- lexicographic order of the points, components of a node together
+  // (alfd_host_numbering_from_points) -- and the brick row blocks of A (alfd_host_brick_blocks_from_points);
+  // set_matrix / set_prolongator then permute what they upload, and every vector that crosses the ABI
+  // (vmult, solve, augment_rhs) is permuted on the way in and back on the way out: the caller keeps its numbering.
+  template <class PointContainer>
+  void set_numbering_from_support_points(const PointContainer &points, int dim, const int32_t brick[3] = nullptr) {
+    const int64_t n = (int64_t)points.size();
+    std::vector<double> xyz((size_t)n * dim), sorted((size_t)n * dim);
+    int64_t i = 0;
+    for (const auto &p : points) {
+      for (int d = 0; d < dim; ++d) xyz[(size_t)i * dim + d] = p[d];
+      ++i;
+    }
+    new_to_old_.assign((size_t)n, 0);
+    old_to_new_.assign((size_t)n, 0);
+    check(alfd_host_numbering_from_points(n, dim, xyz.data(), new_to_old_.data()));
+    for (int64_t k = 0; k < n; ++k) {
+      old_to_new_[new_to_old_[k]] = k;
+      for (int d = 0; d < dim; ++d) sorted[(size_t)k * dim + d] = xyz[(size_t)new_to_old_[k] * dim + d];
+    }
+    static const int32_t default_brick[3] = {16, 4, 1};
+    std::vector<int64_t> ptr((size_t)n + 1);
+    std::vector<int32_t> rows((size_t)n);
+    int64_t nb = 0;
+    check(alfd_host_brick_blocks_from_points(n, dim, sorted.data(), brick ? brick : default_brick, 250, &nb, ptr.data(),
+                                             rows.data()));
+    check(alfd_set_row_blocks(ctx_, ALFD_A, nb, ptr.data(), rows.data()));
+    in0_.assign((size_t)n, 0.0);
+    out0_.assign((size_t)n, 0.0);
+  }
+  bool renumbered() const { return !new_to_old_.empty(); }
+
+  // CSR prolongator of a multigrid level (alfd_set_prolongator), e.g. from MGTransferPrebuilt or
+  // FETools::get_interpolation_matrix; the rows of level 0 follow the block-0 renumbering.
+  template <class SparseMatrixType>
+  void set_prolongator(int level, const SparseMatrixType &P) {
+    const int64_t nrows = (int64_t)P.m();
+    const bool prow = level == 0 && !new_to_old_.empty();
+    std::vector<int64_t> rp(nrows + 1, 0);
+    std::vector<int32_t> col;
+    std::vector<double> val;
+    std::vector<std::pair<int32_t, double>> row;
+    for (int64_t r = 0; r < nrows; ++r) {
+      row.clear();
+      const int64_t src = prow ? new_to_old_[r] : r;
+      for (auto it = P.begin(src); it != P.end(src); ++it) row.emplace_back((int32_t)it->column(), it->value());
+      std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+      for (const auto &e : row) {
+        col.push_back(e.first);
+        val.push_back(e.second);
+      }
+      rp[r + 1] = (int64_t)col.size();
+    }
+    check(alfd_set_prolongator(ctx_, level, nrows, (int64_t)P.n(), rp.data(), col.data(), val.data()));
   }
 
   template <class VectorType>
@@ -160,8 +228,9 @@ class System {
   // f += gamma Ct invW g  (stokes...:1012-1018)
   template <class BlockVectorType>
   void augment_rhs(BlockVectorType &rhs) {
-    std::vector<double *> p = ptrs(rhs);
+    std::vector<double *> p = out_ptrs(rhs, /*load=*/true);
     check(alfd_augment_rhs(ctx_, p.data()));
+    finish_out(rhs);
   }
 
   // The block_operator AA (stokes...:1000-1003) as an object with vmult().
@@ -170,9 +239,10 @@ class System {
     explicit SystemOperator(System &s) : sys_(&s) {}
     template <class BlockVectorType>
     void vmult(BlockVectorType &dst, const BlockVectorType &src) const {
-      std::vector<const double *> s = cptrs(src);
-      std::vector<double *> d = ptrs(dst);
+      std::vector<const double *> s = sys_->in_ptrs(src);
+      std::vector<double *> d = sys_->out_ptrs(dst, false);
       sys_->check(alfd_system_apply(sys_->ctx_, s.data(), d.data()));
+      sys_->finish_out(dst);
     }
     System *system() const { return sys_; }
 
@@ -187,6 +257,33 @@ class System {
     if (rc == ALFD_E_NO_CONVERGENCE_OUTER || rc == ALFD_E_NO_CONVERGENCE_INNER)
       throw NoConvergence(rc, msg, step, res);
     throw Error(rc, msg);
+  }
+
+  // block pointers for the ABI; with a front-end renumbering block 0 goes through staging copies in the new order
+  template <class BlockVectorType>
+  std::vector<const double *> in_ptrs(const BlockVectorType &v) {
+    std::vector<const double *> p = cptrs(v);
+    if (!new_to_old_.empty()) {
+      for (size_t k = 0; k < new_to_old_.size(); ++k) in0_[k] = p[0][new_to_old_[k]];
+      p[0] = in0_.data();
+    }
+    return p;
+  }
+  template <class BlockVectorType>
+  std::vector<double *> out_ptrs(BlockVectorType &v, bool load) {
+    std::vector<double *> p = ptrs(v);
+    if (!new_to_old_.empty()) {
+      if (load)
+        for (size_t k = 0; k < new_to_old_.size(); ++k) out0_[k] = p[0][new_to_old_[k]];
+      p[0] = out0_.data();
+    }
+    return p;
+  }
+  template <class BlockVectorType>
+  void finish_out(BlockVectorType &v) {
+    if (new_to_old_.empty()) return;
+    double *b0 = &*v.block(0).begin();
+    for (size_t k = 0; k < new_to_old_.size(); ++k) b0[new_to_old_[k]] = out0_[k];
   }
 
   template <class BlockVectorType>
@@ -206,6 +303,8 @@ class System {
   alfd_ctx_t ctx_ = nullptr;
   alfd_config cfg_{};
   int w_inverse_ = -1;
+  std::vector<int64_t> new_to_old_, old_to_new_;   // front-end renumbering of block 0 (empty: none)
+  std::vector<double> in0_, out0_;                  // staging of block-0 vectors in the library's numbering
   friend class SystemOperator;
 };
 
@@ -220,10 +319,11 @@ class ALPreconditioner {
   // void vmult(BlockVector<double>& v, const BlockVector<double>& u) const
   template <class BlockVectorType>
   void vmult(BlockVectorType &v, const BlockVectorType &u) const {
-    std::vector<const double *> s = System::cptrs(u);
-    std::vector<double *> d = System::ptrs(v);
+    std::vector<const double *> s = sys_->in_ptrs(u);
+    std::vector<double *> d = sys_->out_ptrs(v, false);
     alfd_result res{};
     sys_->check(alfd_precond_apply(sys_->handle(), s.data(), d.data(), &res));
+    sys_->finish_out(v);
     last_ = res;
   }
   const alfd_result &last_result() const { return last_; }
@@ -262,9 +362,10 @@ class GpuKrylovSolver {
   void solve(const MatrixType &A, BlockVectorType &x, const BlockVectorType &b, const PreconditionerType &P) {
     if (A.system() != sys_ || P.system() != sys_)
       throw Error(ALFD_E_INVALID, "operator, preconditioner and solver must share one System");
-    std::vector<const double *> rhs = System::cptrs(b);
-    std::vector<double *> sol = System::ptrs(x);
+    std::vector<const double *> rhs = sys_->in_ptrs(b);
+    std::vector<double *> sol = sys_->out_ptrs(x, /*load=*/true);   // x carries the initial guess
     const int rc = alfd_solve(sys_->handle(), rhs.data(), sol.data(), &last_);
+    sys_->finish_out(x);
     sys_->check(rc, (unsigned int)last_.outer_iterations, last_.last_residual);
   }
   unsigned int last_step() const { return (unsigned int)last_.outer_iterations; }   // SolverControl::last_step()

@@ -4,6 +4,9 @@
 //   elliptic   elliptic_interface.cc:680-906: EllipticInterfacePreconditioners::
 //              BlockTriangularALPreconditionerModified + SolverFGMRES (restart 50), W^-1 = 1/(M^2)_ii
 //   rational   immersed_laplace.cc:585-631: RationalPreconditioner + SolverMinRes
+//   renumbered stokes_immersed_boundary.cc:918-1079 on a cell-wise assembled 3-D Taylor-Hood system whose velocity DoFs
+//              carry a scrambled numbering (stand-in for Cuthill-McKee, :533-541): solved as handed over and through
+//              System::set_numbering_from_support_points; both solutions must agree in the CALLER's numbering
 //   export F   dump the default system to the .alfd wire format (no GPU)
 // Prints "outer=<n> inner=<n> ..."; exit code 3 if no GPU context can be created.
 #include <algorithm>
@@ -144,10 +147,100 @@ static int run_rational() {
   return 0;
 }
 
+// stokes_immersed_boundary.cc:918-1079 with the front-end renumbering of the adapter
+static int run_renumbered() {
+  using namespace alfd::dealii_adapter;
+  alfd_synth_params sp;
+  base_params(sp);
+  sp.dim = 3, sp.degree = 2, sp.ncomp = 3, sp.n_cells = 6, sp.lo = 0, sp.hi = 1, sp.stokes = 1, sp.grad_div = 1;
+  sp.gamma_grad_div = 10.0, sp.coupling_nq = 4, sp.immersed_refine = 0, sp.radius = 0.1, sp.assembly = 1;
+  sp.center[0] = sp.center[1] = sp.center[2] = 0.5;
+  sp.body_force[0] = 1.0, sp.embedded_value[0] = -1.0, sp.embedded_value[1] = 1.0;
+  char err[256];
+  void *h = alfd_synth_generate(&sp, err, 256);
+  if (!h) return std::fprintf(stderr, "generator: %s\n", err), 2;
+  const int n1 = 2 * sp.n_cells + 1;
+  const int64_t nn = (int64_t)n1 * n1 * n1;
+  // a scrambled node numbering (multiplicative hash order: deterministic, far from lexicographic)
+  std::vector<int64_t> new_to_old(nn);
+  for (int64_t k = 0; k < nn; ++k) new_to_old[k] = k;
+  std::sort(new_to_old.begin(), new_to_old.end(), [](int64_t a, int64_t b) {
+    const uint64_t ha = (uint64_t)a * 0x9E3779B97F4A7C15ull, hb = (uint64_t)b * 0x9E3779B97F4A7C15ull;
+    return ha != hb ? ha < hb : a < b;
+  });
+  if (alfd_synth_permute_nodes(h, new_to_old.data(), nn) != 0) return std::fprintf(stderr, "permute failed\n"), 2;
+  mock::SparseMatrix A = load(h, "A"), Bt = load(h, "Bt"), Ct = load(h, "Ct"), Mp = load(h, "Mp"), M = load(h, "M");
+  const size_t n_u = A.m(), n_p = Mp.m(), n_l = M.m();
+  mock::Vector inverse_squares(n_l), pressure_diagonal_inv(n_p);
+  for (size_t i = 0; i < n_l; ++i) inverse_squares[i] = 1. / (M.diag_element(i) * M.diag_element(i));
+  for (size_t i = 0; i < n_p; ++i) {
+    double srow = 0;
+    for (auto it = Mp.begin(i); it != Mp.end(i); ++it) srow += it->value();
+    pressure_diagonal_inv[i] = 1. / srow;
+  }
+  // support points of the velocity DoFs in the caller's (scrambled) numbering
+  std::vector<std::array<double, 3>> support_points(n_u);
+  for (int64_t k = 0; k < nn; ++k) {
+    const int64_t o = new_to_old[k];
+    const std::array<double, 3> pt = {(double)(o % n1) / (n1 - 1), (double)((o / n1) % n1) / (n1 - 1), (double)(o / ((int64_t)n1 * n1)) / (n1 - 1)};
+    for (int c = 0; c < 3; ++c) support_points[3 * k + c] = pt;
+  }
+  int64_t nf, ng, nrp;
+  const double *f, *g, *rp;
+  alfd_synth_vector(h, "f", &nf, &f);
+  alfd_synth_vector(h, "g", &ng, &g);
+  alfd_synth_vector(h, "rhs_p", &nrp, &rp);
+  mock::BlockVector x[2] = {mock::BlockVector({n_u, n_p, n_l}), mock::BlockVector({n_u, n_p, n_l})};
+  unsigned int outer[2] = {0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    System gpu(0);
+    if (pass == 1) gpu.set_numbering_from_support_points(support_points, 3);
+    gpu.set_matrix(ALFD_A, A);
+    gpu.set_matrix(ALFD_BT, Bt);
+    gpu.set_matrix(ALFD_CT, Ct);
+    gpu.set_matrix(ALFD_MP, Mp);
+    gpu.set_diag(ALFD_INVW, inverse_squares);
+    gpu.set_diag(ALFD_MP_LUMPED_INV, pressure_diagonal_inv);
+    alfd_config cfg;
+    alfd_default_config(&cfg, ALFD_AL_STOKES);
+    cfg.inner.max_steps = 1000;
+    gpu.configure(cfg);
+    gpu.setup();
+    mock::BlockVector rhs({n_u, n_p, n_l});
+    for (size_t i = 0; i < n_u; ++i) rhs.block(0)[i] = f[i];
+    for (size_t i = 0; i < n_p; ++i) rhs.block(1)[i] = rp[i];
+    for (size_t i = 0; i < n_l; ++i) rhs.block(2)[i] = g[i];
+    gpu.augment_rhs(rhs);
+    auto AA = gpu.system_operator();
+    BlockPreconditionerAugmentedLagrangianStokes P(gpu);
+    SolverFGMRES<mock::BlockVector> solver(gpu);
+    solver.solve(AA, x[pass], rhs, P);
+    outer[pass] = solver.last_step();
+    // the operator through the adapter: || rhs - AA x || in the caller's numbering
+    mock::BlockVector ax({n_u, n_p, n_l});
+    AA.vmult(ax, x[pass]);
+    double r2 = 0;
+    for (unsigned b = 0; b < 3; ++b)
+      for (size_t i = 0; i < ax.block(b).size(); ++i) r2 += (rhs.block(b)[i] - ax.block(b)[i]) * (rhs.block(b)[i] - ax.block(b)[i]);
+    std::printf("pass=%d renumbered=%d outer=%u inner=%lld residual=%.6e true_residual=%.6e\n", pass, (int)gpu.renumbered(),
+                outer[pass], (long long)solver.last_result().inner_iterations, solver.last_value(), std::sqrt(r2));
+  }
+  double dmax = 0, xmax = 0;
+  for (unsigned b = 0; b < 3; ++b)
+    for (size_t i = 0; i < x[0].block(b).size(); ++i) {
+      dmax = std::max(dmax, std::fabs(x[0].block(b)[i] - x[1].block(b)[i]));
+      xmax = std::max(xmax, std::fabs(x[0].block(b)[i]));
+    }
+  std::printf("solution_difference=%.3e of %.3e\n", dmax, xmax);
+  alfd_synth_free(h);
+  return dmax <= 1e-6 * xmax ? 0 : 4;
+}
+
 int main(int argc, char **argv) {
   using namespace alfd::dealii_adapter;
-  if (argc > 1 && (std::string(argv[1]) == "elliptic" || std::string(argv[1]) == "rational")) {
+  if (argc > 1 && (std::string(argv[1]) == "elliptic" || std::string(argv[1]) == "rational" || std::string(argv[1]) == "renumbered")) {
     try {
+      if (std::string(argv[1]) == "renumbered") return run_renumbered();
       return std::string(argv[1]) == "elliptic" ? run_elliptic() : run_rational();
     } catch (const NoConvergence &e) {
       std::fprintf(stderr, "NoConvergence at step %u: %s\n", e.last_step, e.what());

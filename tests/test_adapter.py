@@ -48,6 +48,22 @@ def test_adapter_elliptic_and_rational_call_sites_match_golden(demo, mode, case)
         assert f"rational={gold['rational_iterations']} " in first and "refused=1" in p.stdout
 
 
+@pytest.mark.gpu
+def test_adapter_front_end_renumbering(demo):
+    """System::set_numbering_from_support_points: a 3-D Taylor-Hood system in a scrambled DoF numbering solved as handed
+    over and through the adapter's renumbering (operators permuted at upload, vectors on the way in and out): same
+    outer count, same solution in the caller's numbering, true residual below the stop rule in both passes."""
+    p = subprocess.run([demo, "renumbered"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.splitlines()
+    assert "renumbered=0" in lines[0] and "renumbered=1" in lines[1]
+    o0 = int(lines[0].split("outer=")[1].split()[0])
+    o1 = int(lines[1].split("outer=")[1].split()[0])
+    assert abs(o0 - o1) <= 1
+    for ln in lines[:2]:
+        assert float(ln.split("true_residual=")[1]) <= 1e-6
+
+
 def test_cpp_exporter_round_trips_through_the_wire_format(demo, tmp_path):
     """include/alfd/dealii_export.hpp (driven through the mock SparseMatrix with
     diagonal-first rows) -> .alfd file -> opfile.load(): identical to the Python-side
