@@ -1901,14 +1901,16 @@ static int upload_vec(alfd_ctx *ctx, DevCsr &m, T **dst, const std::vector<T> &v
 }
 
 static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32_t *col, const double *val,
-                        bool slot_is_user) {
+                        bool slot_is_user, bool skip_vi = false) {
   WindowParams wp;
   wp.RB_long = ctx->win_RB;
   wp.short_scale = ctx->win_short_scale;
   wp.RB_vi = ctx->win_RB_vi;
   wp.maxW = ctx->win_maxW;
   wp.gap = ctx->win_gap;
-  wp.want_vi = ctx->win_vi && (slot_is_user || ctx->vi_levels);
+  // skip_vi: the batch-major form already holds the matrix with dictionaries of its own; the window plan then only
+  // provides the 16-bit columns of the general 10 B/nnz kernel (a third of the planning time at N = 74)
+  wp.want_vi = !skip_vi && ctx->win_vi && (slot_is_user || ctx->vi_levels);
   WindowPlan pl;
   plan_window(m.nrows, m.L, rp, col, val, wp, pl);
   if (!pl.win) return ALFD_OK;
@@ -2784,11 +2786,12 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
   const bool win_long = m.L == 64 && m.nrows >= (int64_t)ctx->win_RB * ctx->win_min_blocks;
   const bool win_short = ctx->win_short_scale > 0 && m.L >= 8 && m.L < 64 &&
                          m.nrows >= (int64_t)std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / m.L) * ctx->win_short_min_blocks;
-  if (ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0)
-    RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot));
-  // the batch-major form has dictionaries of its own (per row block, up to 1024 values with wide codes): it is tried
-  // even when the 96-row window blocks above could not be coded (cell-wise assembled operators)
-  if (ctx->vs_enable && m.win && (m.vi || ctx->vs_wide) && m.L == 64) RC(build_vs(ctx, m, slot, rp, col_up, val));
+  const bool windows = ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0;
+  // long rows: the batch-major form first -- it has dictionaries of its own (per row block, up to 1024 values with wide
+  // codes) and is tried even when 96-row window blocks cannot be coded (cell-wise assembled operators)
+  if (windows && ctx->vs_enable && ctx->win_vi && m.L == 64 && (slot != kScratchSlot || ctx->vi_levels))
+    RC(build_vs(ctx, m, slot, rp, col_up, val));
+  if (windows) RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot, m.vs.on));
   if (ctx->vs_enable && m.win && (m.L == 32 || m.L == 16 || m.L == 8)) RC(build_vss(ctx, m, rp, col_up, val));
   m.present = true;
   return ALFD_OK;
@@ -4909,7 +4912,7 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   out->window_blocks = m.win_nblocks;
   out->window_fallback_blocks = m.win_fallback_blocks;
   out->value_indexed_blocks = m.vi_blocks;
-  out->value_indexed_nnz = m.vi_nnz;
+  out->value_indexed_nnz = m.vs.on && ctx->vs_enable ? m.nnz : m.vi_nnz;   // every entry of a batch-major matrix is dictionary-coded
   out->dictionary_entries = m.vi_dict_total;
   out->value_wide_nnz = m.vi_wide_nnz;
   out->algorithmic_bytes = m.algorithmic_bytes();
