@@ -289,7 +289,8 @@ struct alfd_ctx {
   int win_RB_vi = 96;                       // row block of value-indexed matrices (ALFD_SPMV_WINDOW_RB_VI)
   int win_vi = 1;                           // dictionary-coded values in window blocks (ALFD_SPMV_VALUE_INDEX)
   int win_short_scale = 2;                  // short-row block = min(512, win_RB * scale * 64 / L) rows; 0 = off
-  int vs_enable = 1, vs_NW = 4, vs_RB = 96, vs_xcd = 0, vs_share = 1, vs_wide = 1;   // batch-major format (alfd_set_tunable "batch_major")
+  int vs_enable = 1, vs_NW = 4, vs_RB = 96, vs_xcd = 0, vs_share = 1, vs_wide = 1;
+  int vs_lds_base_ok = -1;                  // -1 unknown; the absolute LDS addressing of kernels_vs.hpp needs base 0   // batch-major format (alfd_set_tunable "batch_major")
   std::vector<int64_t> rb_ptr[ALFD_NSLOTS + 1];   // row-block hint per slot (alfd_set_row_blocks)
   std::vector<int32_t> rb_rows[ALFD_NSLOTS + 1];
   int win_short_min_blocks = 256;           // the same for short-row matrices (ALFD_SPMV_WINDOW_SHORT_MIN_BLOCKS; 64 costs cfg 3 30 %, 1024 leaves its 262 k-row level operator out)
@@ -687,6 +688,19 @@ static void launch_vss(alfd_ctx *ctx, const DevCsr &m, const double *x, double *
 static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
                       const double *d, double *y2) {
   const DevCsr::Vs &v = m.vs;
+  if (ctx->vs_lds_base_ok < 0) {   // first batch-major launch of this context: does dynamic LDS start at offset 0?
+    uint32_t *probe = nullptr, base = 1;
+    if (hipMalloc((void **)&probe, sizeof(uint32_t)) == hipSuccess) {
+      hipLaunchKernelGGL(vs_lds_base_probe_kernel, dim3(1), dim3(64), 4096, ctx->stream, probe);
+      hipMemcpyAsync(&base, probe, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+      hipStreamSynchronize(ctx->stream);
+      hipFree(probe);
+    }
+    ctx->vs_lds_base_ok = base == 0 ? 1 : 0;
+    if (!ctx->vs_lds_base_ok)
+      std::fprintf(stderr, "[alfd] dynamic LDS does not start at offset 0 (%u): batch-major SpMV formats disabled\n", base);
+  }
+  if (!ctx->vs_lds_base_ok) return false;
   if (v.L == 32) return launch_vss<32>(ctx, m, x, y, epi, alpha, d, y2), true;
   if (v.L == 16) return launch_vss<16>(ctx, m, x, y, epi, alpha, d, y2), true;
   if (v.L == 8) return launch_vss<8>(ctx, m, x, y, epi, alpha, d, y2), true;
@@ -2560,7 +2574,16 @@ static void plan_vss(int64_t nrows, int L, const int64_t *rp, const int32_t *col
 
 static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const int32_t *col, const double *val) {
   VsPlan pl;
-  const bool hint = slot >= 0 && slot < ALFD_NSLOTS && !ctx->rb_ptr[slot].empty();
+  bool hint = slot >= 0 && slot < ALFD_NSLOTS && !ctx->rb_ptr[slot].empty();
+  if (hint && ctx->rb_ptr[slot].back() != m.nrows) {
+    // the hint was given for a matrix of another size (a re-upload of the slot): it no longer applies
+    if (ctx->cfg.log_level > 0)
+      std::fprintf(stderr, "[alfd] row-block hint of slot %d dropped: it lists %lld rows, the matrix has %lld\n", slot,
+                   (long long)ctx->rb_ptr[slot].back(), (long long)m.nrows);
+    ctx->rb_ptr[slot].clear();
+    ctx->rb_rows[slot].clear();
+    hint = false;
+  }
   if (hint) {
     // the hint must list every row exactly once
     const auto &bp = ctx->rb_ptr[slot];
@@ -5333,6 +5356,12 @@ int alfd_set_row_blocks(alfd_ctx_t ctx, int slot, int64_t n_blocks, const int64_
   ctx->rb_ptr[slot].clear();
   ctx->rb_rows[slot].clear();
   if (n_blocks <= 0 || !block_ptr || !rows) return ALFD_OK;   // hint removed
+  // the prefix is checked before anything is copied with it (a negative, huge or non-monotone value would be
+  // undefined behaviour in vector::assign); that the blocks partition the rows is checked against the matrix at upload
+  if (block_ptr[0] != 0) return ctx->err = "alfd_set_row_blocks: block_ptr[0] must be 0", ALFD_E_INVALID;
+  for (int64_t b = 0; b < n_blocks; ++b)
+    if (block_ptr[b + 1] < block_ptr[b]) return ctx->err = "alfd_set_row_blocks: block_ptr must be monotone", ALFD_E_INVALID;
+  if (block_ptr[n_blocks] > 2147483000LL) return ctx->err = "alfd_set_row_blocks: more than 2^31 rows", ALFD_E_INVALID;
   ctx->rb_ptr[slot].assign(block_ptr, block_ptr + n_blocks + 1);
   ctx->rb_rows[slot].assign(rows, rows + block_ptr[n_blocks]);
   return ALFD_OK;

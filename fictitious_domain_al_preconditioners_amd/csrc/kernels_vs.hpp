@@ -64,6 +64,15 @@ __device__ __forceinline__ double vs_lds_f64(uint32_t byte_off) {
   return *(const __attribute__((address_space(3))) double *)(uintptr_t)byte_off;
 }
 
+// The kernels of this file read LDS at ABSOLUTE byte offsets (vs_lds_f64), which is right only while their dynamic
+// __shared__ array starts at LDS address 0, i.e. while neither they nor anything they call owns static LDS.  This
+// one-workgroup probe has the same property (dynamic LDS only) and reports where its array starts; the library runs it
+// once per context and refuses the batch-major formats if the answer is not 0.
+__global__ void vs_lds_base_probe_kernel(uint32_t *out) {
+  extern __shared__ double xs[];
+  if (threadIdx.x == 0) out[0] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(char *)xs;
+}
+
 struct VsWord3 {
   uint32_t x, y, z;
 };

@@ -182,6 +182,8 @@ class SyntheticProblem:
         """W^-1 = 1 / (M M)_ii, the true diagonal of M^2 (utilities.h:348-374,
         elliptic_interface.cc:726)."""
         m = self.mats["M"]          # M is symmetric: (M M)_ii = sum_k M_ik^2, row-local (works on a row slice)
+        if not np.all(np.diff(m.row_ptr) > 0):      # reduceat would return a neighbour's entry for an empty row
+            raise ValueError("the immersed mass matrix has an empty row")
         return 1.0 / np.add.reduceat(m.val * m.val, m.row_ptr[:-1])
 
     def rho_bound(self) -> float:

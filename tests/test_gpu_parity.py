@@ -227,6 +227,9 @@ def test_spmv_every_kernel_family_bitwise(built):
     ctx = solver.Context(0)
     try:
         for name, m in mats.items():
+            # the round-1 value-indexed window forms (8-bit / 16-bit codes, raw blocks) are planned only when the
+            # batch-major form does not take the matrix: switched off here so that those kernels stay covered
+            ctx.set_tunable("batch_major", 0 if name in expect_format else 1)
             ctx.set_matrix(_abi.A, m)
             info = ctx.matrix_info(_abi.A)
             fmt = expect_format.get(name)
@@ -544,6 +547,32 @@ def test_properties_at_bench_scale(built):
     assert np.array_equal(ctx.history(), h1) and all(np.array_equal(p_, q_) for p_, q_ in zip(x, x2))
     assert np.all(np.diff(h1) <= 0)
     ctx.close()
+
+
+def test_row_block_hint_validation_and_stale_hint(built):
+    """alfd_set_row_blocks refuses a prefix that does not start at 0 / is not monotone before copying anything with it;
+    a hint given for a matrix of another size is dropped at the next upload of the slot (runs of the numbering take
+    over) instead of failing the upload."""
+    big = problems.generate(dim=3, degree=2, ncomp=3, n_cells=14, stokes=False, grad_div=True, gamma_grad_div=10.0,
+                            radius=0.1, immersed_refine=0)       # 73 k rows: both sizes take the window / batch-major forms
+    small = problems.generate(dim=3, degree=2, ncomp=3, n_cells=13, stokes=False, grad_div=True, gamma_grad_div=10.0,
+                              radius=0.1, immersed_refine=0)
+    ctx = solver.Context(0)
+    try:
+        bp, rows = problems.brick_row_blocks(big.params, (8, 4, 2))
+        for bad in (np.r_[1, bp[1:]], np.r_[bp[:3], bp[1], bp[4:]], np.r_[bp[:-1], -5]):
+            with pytest.raises(solver.AlfdError):
+                ctx.set_row_blocks(_abi.A, bad.astype(np.int64), rows)
+        ctx.set_row_blocks(_abi.A, bp, rows)
+        ctx.set_matrix(_abi.A, big.mats["A"])
+        assert ctx.matrix_info(_abi.A)["batch_major"] == 2
+        ctx.set_matrix(_abi.A, small.mats["A"])                  # other row count: the hint no longer applies
+        assert ctx.matrix_info(_abi.A)["batch_major"] == 1       # runs of the numbering
+        x = _rng_vec(small.mats["A"].ncols, 5)
+        got, lanes = ctx.spmv(_abi.A, x, np.zeros(small.mats["A"].nrows))
+        assert np.array_equal(got, oracle.spmv(small.mats["A"], x, lanes=lanes)[0])
+    finally:
+        ctx.close()
 
 
 def test_mid_size_solve_with_the_bench_kernels_matches_oracle(built):
