@@ -81,6 +81,7 @@ struct DevCsr {
   std::vector<void *> owned;  // device arrays of this matrix (released on re-upload / destroy)
   // LDS-window format (long-row matrices): see spmv_window_kernel
   bool win = false;
+  bool win_deferred = false, win_user = true;   // window plan not built yet (the batch-major form holds the matrix)
   int tag = 0;  // 1 = multigrid level matrix (separate kernel instantiation for profiling)
   int32_t win_RB = 0, win_maxW = 0;
   int64_t win_nblocks = 0, win_fallback_blocks = 0, win_nseg = 0;
@@ -246,6 +247,7 @@ struct alfd_ctx {
   std::vector<MlLevel> ml;
   int ml_rep_level = -1;                      // first replicated level (multi-rank), -1: none
   int64_t ml_rep_threshold = 300000;          // replicate levels with at most this many unknowns (ALFD_ML_REPLICATE)
+  int ml_gpu_galerkin = 1;                    // Galerkin products of CSR-prolongator levels on the device (ALFD_ML_GPU_GALERKIN)
   double *g_w = nullptr, *g_tlam = nullptr;   // global W^-1 diagonal and multiplier work vector of the replicated levels
   std::vector<int64_t> ml_coff[ALFD_MAX_LEVELS];       // rank offsets of the coarse dofs of each level
   const int64_t *up_col_offsets = nullptr;             // upload_matrix overrides (level matrices)
@@ -2691,6 +2693,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
                          const int32_t *col, const double *val) {
   DevCsr &m = ctx->mat[slot];
   csr_free(m);  // a re-upload releases the previous arrays of this slot
+  const auto t_up0 = std::chrono::steady_clock::now();
   m.nrows = nrows;
   m.ncols = ncols;
   m.nnz = rp[nrows];
@@ -2810,11 +2813,23 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
   const bool win_short = ctx->win_short_scale > 0 && m.L >= 8 && m.L < 64 &&
                          m.nrows >= (int64_t)std::min(512, ctx->win_RB * ctx->win_short_scale * 64 / m.L) * ctx->win_short_min_blocks;
   const bool windows = ctx->win_enable && (win_long || win_short) && !m.sparse && m.nnz > 0;
+  const auto t_plan0 = std::chrono::steady_clock::now();
   // long rows: the batch-major form first -- it has dictionaries of its own (per row block, up to 1024 values with wide
   // codes) and is tried even when 96-row window blocks cannot be coded (cell-wise assembled operators)
   if (windows && ctx->vs_enable && ctx->win_vi && m.L == 64 && (slot != kScratchSlot || ctx->vi_levels))
     RC(build_vs(ctx, m, slot, rp, col_up, val));
-  if (windows) RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot, m.vs.on));
+  const auto t_plan1 = std::chrono::steady_clock::now();
+  // a matrix the batch-major form holds needs the window plan (16-bit columns of the general 10 B/nnz kernel) only
+  // when that kernel is asked for (tunables "value_index" / "batch_major" = 0, alfd_bench_spmv_format(..., 0)):
+  // planned then, from the device copy (ensure_window_plan) -- 1.5 s of the upload at N = 74 otherwise
+  m.win_deferred = windows && m.vs.on && m.L == 64;
+  m.win_user = slot != kScratchSlot;
+  if (windows && !m.win_deferred) RC(build_window(ctx, m, rp, col_up, val, slot != kScratchSlot, m.vs.on));
+  if ((ctx->cfg.log_level > 0 || std::getenv("ALFD_LOG_UPLOAD")) && m.nnz > 50000000)
+    std::fprintf(stderr, "[alfd] upload of a %lld-nnz matrix: CSR copy %.2f s, batch-major plan + copy %.2f s, window plan + copy %.2f s\n",
+                 (long long)m.nnz, std::chrono::duration<double>(t_plan0 - t_up0).count(),
+                 std::chrono::duration<double>(t_plan1 - t_plan0).count(),
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_plan1).count());
   if (ctx->vs_enable && m.win && (m.L == 32 || m.L == 16 || m.L == 8)) RC(build_vss(ctx, m, rp, col_up, val));
   m.present = true;
   return ALFD_OK;
@@ -2958,6 +2973,24 @@ static int download_csr(alfd_ctx *ctx, const DevCsr &m, HostCsr &h) {
     HIPC(hipMemcpyAsync(h.rp.data(), m.rp, (m.nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));
   }
+  return ALFD_OK;
+}
+
+// The deferred window plan of a matrix held in the batch-major form (upload_matrix), built from its device copy.
+static int ensure_window_plan(alfd_ctx *ctx, DevCsr &m) {
+  if (!m.present || !m.win_deferred) return ALFD_OK;
+  HostCsr h;
+  RC(download_csr(ctx, m, h));
+  m.win_deferred = false;
+  const int tag = m.tag;
+  RC(build_window(ctx, m, h.rp.data(), h.col.data(), h.val.data(), m.win_user, true));
+  m.tag = tag;
+  return ALFD_OK;
+}
+static int ensure_window_plans(alfd_ctx *ctx) {
+  for (DevCsr &m : ctx->mat) RC(ensure_window_plan(ctx, m));
+  for (MlLevel &L : ctx->ml)
+    for (DevCsr *m : {&L.A, &L.gA}) RC(ensure_window_plan(ctx, *m));
   return ALFD_OK;
 }
 
@@ -3329,8 +3362,130 @@ static void extract_host(const HostCsr &A, const std::vector<int32_t> &rows, con
 static int upload_level(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h);
 static int level_op(alfd_ctx *ctx, int l, const double *x, double *y);
 
+// A CSR matrix in plain device arrays (intermediate products of the Galerkin setup)
+struct DevRawCsr {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int64_t *rp = nullptr;
+  int32_t *col = nullptr;
+  double *val = nullptr;
+  void release() {
+    if (rp) hipFree(rp);
+    if (col) hipFree(col);
+    if (val) hipFree(val);
+    rp = nullptr, col = nullptr, val = nullptr;
+  }
+};
+
+// out = A * P on the device (spgemm_rows_kernel: the canonical fma chains of spgemm_host, bit for bit).
+// *fits = false when a row has more distinct columns than the kernel's hash set holds (nothing is returned then).
+static int dev_spgemm(alfd_ctx *ctx, int64_t nrows, const int64_t *arp, const int32_t *acol, const double *aval,
+                      const int64_t *prp, const int32_t *pcol, const double *pval, int64_t ncols_out, DevRawCsr &out,
+                      bool *fits) {
+  *fits = false;
+  out = DevRawCsr();
+  out.nrows = nrows;
+  out.ncols = ncols_out;
+  int32_t *counts = nullptr, *ovf = nullptr;
+  HIPC(hipMalloc((void **)&counts, std::max<int64_t>(nrows, 1) * sizeof(int32_t)));
+  HIPC(hipMalloc((void **)&ovf, sizeof(int32_t)));
+  HIPC(hipMemsetAsync(ovf, 0, sizeof(int32_t), ctx->stream));
+  HIPC(hipMalloc((void **)&out.rp, (nrows + 1) * sizeof(int64_t)));
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nrows, 256 * 64));
+  hipLaunchKernelGGL(spgemm_rows_kernel, dim3(grid), dim3(64), 0, ctx->stream, nrows, arp, acol, aval, prp, pcol, pval, 0,
+                     counts, (const int64_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, ovf);
+  std::vector<int32_t> hc(nrows);
+  int32_t hovf = 0;
+  HIPC(hipMemcpyAsync(hc.data(), counts, nrows * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipMemcpyAsync(&hovf, ovf, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  if (hovf) {
+    hipFree(counts);
+    hipFree(ovf);
+    out.release();
+    return ALFD_OK;
+  }
+  std::vector<int64_t> rp(nrows + 1, 0);
+  for (int64_t i = 0; i < nrows; ++i) rp[i + 1] = rp[i] + hc[i];
+  out.nnz = rp[nrows];
+  HIPC(hipMemcpyAsync(out.rp, rp.data(), (nrows + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMalloc((void **)&out.col, std::max<int64_t>(out.nnz, 1) * sizeof(int32_t)));
+  HIPC(hipMalloc((void **)&out.val, std::max<int64_t>(out.nnz, 1) * sizeof(double)));
+  hipLaunchKernelGGL(spgemm_rows_kernel, dim3(grid), dim3(64), 0, ctx->stream, nrows, arp, acol, aval, prp, pcol, pval, 1,
+                     counts, (const int64_t *)out.rp, out.col, out.val, ovf);
+  HIPC(hipGetLastError());
+  HIPC(hipStreamSynchronize(ctx->stream));
+  hipFree(counts);
+  hipFree(ovf);
+  *fits = true;
+  return ALFD_OK;
+}
+
+static int download_raw(alfd_ctx *ctx, const DevRawCsr &d, HostCsr &h) {
+  h.nrows = d.nrows;
+  h.ncols = d.ncols;
+  h.rp.resize(d.nrows + 1);
+  h.col.resize(d.nnz);
+  h.val.resize(d.nnz);
+  HIPC(hipMemcpyAsync(h.rp.data(), d.rp, (d.nrows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (d.nnz) {
+    HIPC(hipMemcpyAsync(h.col.data(), d.col, d.nnz * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(h.val.data(), d.val, d.nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPC(hipStreamSynchronize(ctx->stream));
+  return ALFD_OK;
+}
+
+// Host CSR with the shape of the device matrix A but only the rows that reach the interface patch filled in (the rows
+// with a column in S, which contain S itself): found and gathered on the device, so that the patch setup does not need
+// a host copy of A (21 GB at N = 74).  pos[j] >= 0 marks the columns of S.
+static int fetch_patch_rows(alfd_ctx *ctx, const DevCsr &A, const std::vector<int32_t> &pos, HostCsr &out,
+                            std::vector<int32_t> &Trows) {
+  const int64_t n = A.nrows;
+  int32_t *d_pos = nullptr, *d_rows = nullptr, *d_col = nullptr;
+  uint8_t *d_flag = nullptr;
+  int64_t *d_orp = nullptr;
+  double *d_val = nullptr;
+  HIPC(hipMalloc((void **)&d_pos, std::max<int64_t>(A.ncols, 1) * sizeof(int32_t)));
+  HIPC(hipMalloc((void **)&d_flag, std::max<int64_t>(n, 1)));
+  HIPC(hipMemcpyAsync(d_pos, pos.data(), pos.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(rows_touching_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, n, A.rp, A.col, d_pos, d_flag);
+  std::vector<uint8_t> flag(n);
+  std::vector<int64_t> rp(n + 1);
+  HIPC(hipMemcpyAsync(flag.data(), d_flag, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipMemcpyAsync(rp.data(), A.rp, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  Trows.clear();
+  for (int64_t i = 0; i < n; ++i)
+    if (flag[i]) Trows.push_back((int32_t)i);
+  const int64_t nt = (int64_t)Trows.size();
+  std::vector<int64_t> orp(nt + 1, 0);
+  for (int64_t q = 0; q < nt; ++q) orp[q + 1] = orp[q] + (rp[Trows[q] + 1] - rp[Trows[q]]);
+  const int64_t nnz = orp[nt];
+  HIPC(hipMalloc((void **)&d_rows, std::max<int64_t>(nt, 1) * sizeof(int32_t)));
+  HIPC(hipMalloc((void **)&d_orp, (nt + 1) * sizeof(int64_t)));
+  HIPC(hipMalloc((void **)&d_col, std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
+  HIPC(hipMalloc((void **)&d_val, std::max<int64_t>(nnz, 1) * sizeof(double)));
+  HIPC(hipMemcpyAsync(d_rows, Trows.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPC(hipMemcpyAsync(d_orp, orp.data(), (nt + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  if (nt > 0)
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, ctx->stream, nt, d_rows, A.rp, A.col,
+                       A.val, d_orp, d_col, d_val);
+  out.nrows = n;
+  out.ncols = A.ncols;
+  out.col.resize(nnz);
+  out.val.resize(nnz);
+  HIPC(hipMemcpyAsync(out.col.data(), d_col, nnz * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipMemcpyAsync(out.val.data(), d_val, nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  out.rp.assign(n + 1, 0);
+  for (int64_t q = 0; q < nt; ++q) out.rp[Trows[q] + 1] = orp[q + 1] - orp[q];
+  for (int64_t i = 0; i < n; ++i) out.rp[i + 1] += out.rp[i];
+  for (void *q : {(void *)d_pos, (void *)d_flag, (void *)d_rows, (void *)d_orp, (void *)d_col, (void *)d_val}) hipFree(q);
+  return ALFD_OK;
+}
+
 // S, the patch operators and lambda_max(D^-1 Aug_SS); A / C / Ct are the host copies of the level-0 operators
-static int patch_setup(alfd_ctx *ctx, const HostCsr &A, const HostCsr &C, const HostCsr &Ct) {
+static int patch_setup(alfd_ctx *ctx, const HostCsr *A_full, const HostCsr &C, const HostCsr &Ct) {
   alfd_ctx::Patch &Q = ctx->patch;
   const alfd_config &c = ctx->cfg;
   const int64_t n = ctx->n[0];
@@ -3342,7 +3497,10 @@ static int patch_setup(alfd_ctx *ctx, const HostCsr &A, const HostCsr &C, const 
     }
   const int64_t m = (int64_t)S.size();
   if (m == 0) return ALFD_OK;
-  {
+  HostCsr A_patch;      // without a host copy of A: only the rows that reach the patch, gathered on the device
+  if (!A_full) RC(fetch_patch_rows(ctx, ctx->mat[ALFD_A], pos, A_patch, Trows));
+  const HostCsr &A = A_full ? *A_full : A_patch;
+  if (A_full) {
     // rows of A with a column in S (the rows E^T-corrections reach): scanned in parallel, kept in order
     const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::vector<int32_t>> part(T);
@@ -3753,17 +3911,29 @@ static int ml_setup(alfd_ctx *ctx) {
   };
   std::vector<Stash> stash(nlev + 1);
   HostCsr A, C, Ct, An, Cn, Ctn, P, R;
+  // Host copies: C and Ct are small and always fetched.  A (21 GB at N = 74) only when a level needs it on the host:
+  // the aggregation levels' product, or a CSR-prolongator level whose product does not fit the device kernel.  The
+  // device products (ALFD_ML_GPU_GALERKIN=0 switches them off) and the device-side patch-row gather need no host A.
+  bool have_host_A = false;
+  auto fetch_A = [&](const DevCsr &dA) -> int {
+    if (have_host_A) return ALFD_OK;
+    PhaseClock pc(ctx, ALFD_SETUP_ML_FETCH);
+    RC(download_csr(ctx, dA, A));
+    have_host_A = true;
+    return ALFD_OK;
+  };
   {
     PhaseClock pc(ctx, ALFD_SETUP_ML_FETCH);
-    RC(download_csr(ctx, ctx->mat[ALFD_A], A));
     RC(download_csr(ctx, ctx->mat[ALFD_C], C));
     RC(download_csr(ctx, ctx->mat[ALFD_CT], Ct));
   }
+  const bool gpu_products = ctx->ml_gpu_galerkin && ctx->nranks == 1;
+  if (!gpu_products || ctx->ml_P[0].rp.empty()) RC(fetch_A(ctx->mat[ALFD_A]));
   const int64_t lam0 = ctx->nranks > 1 ? ctx->part[last][rk] : 0;
   const int64_t lam_global = ctx->nranks > 1 ? ctx->part[last].back() : ctx->n[last];
   if (c.ml_patch_degree > 0) {
     PhaseClock pc(ctx, ALFD_SETUP_ML_PATCH);
-    RC(patch_setup(ctx, A, C, Ct));
+    RC(patch_setup(ctx, have_host_A ? &A : nullptr, C, Ct));
   }
   for (int l = 0; l <= nlev; ++l) {
     MlLevel &L = ctx->ml[l];
@@ -3809,31 +3979,58 @@ static int ml_setup(alfd_ctx *ctx) {
     if (!ctx->ml_P[l].rp.empty()) {
       // ---- next level through a general CSR prolongator (single rank): A_c = P^T (A P), C_c = C P, Ct_c = C_c^T
       const HostCsr &Pm = ctx->ml_P[l];
+      MlLevel &Nx = ctx->ml[l + 1];
+      DevCsr &dA = l == 0 ? ctx->mat[ALFD_A] : L.A;
+      DevCsr &dC = l == 0 ? ctx->mat[ALFD_C] : L.C;
       {
+        PhaseClock pc(ctx, ALFD_SETUP_ML_UPLOAD);
+        transpose_host(Pm, R);
+        RC(upload_level_part(ctx, Nx.P, Pm, nullptr, true));
+        RC(upload_level_part(ctx, Nx.R, R, nullptr, true));
+      }
+      bool done = false;
+      if (gpu_products && !dA.sparse && !dC.sparse && !Nx.P.sparse && !Nx.R.sparse && dA.nnz > 0) {
+        // the three products on the device (spgemm_rows_kernel), results fetched for the format planner
+        PhaseClock pc(ctx, ALFD_SETUP_ML_GALERKIN);
+        DevRawCsr AP, RAP, CP;
+        bool f1 = false, f2 = false, f3 = false;
+        RC(dev_spgemm(ctx, dA.nrows, dA.rp, dA.col, dA.val, Nx.P.rp, Nx.P.col, Nx.P.val, Pm.ncols, AP, &f1));
+        if (f1) RC(dev_spgemm(ctx, Nx.R.nrows, Nx.R.rp, Nx.R.col, Nx.R.val, AP.rp, AP.col, AP.val, Pm.ncols, RAP, &f2));
+        AP.release();
+        if (f2) RC(dev_spgemm(ctx, dC.nrows, dC.rp, dC.col, dC.val, Nx.P.rp, Nx.P.col, Nx.P.val, Pm.ncols, CP, &f3));
+        if (f3) {
+          RC(download_raw(ctx, RAP, An));
+          RC(download_raw(ctx, CP, Cn));
+          transpose_host(Cn, Ctn);
+          done = true;
+        }
+        RAP.release();
+        CP.release();
+      }
+      if (!done) {
+        if (l == 0) RC(fetch_A(dA));
         PhaseClock pc(ctx, ALFD_SETUP_ML_GALERKIN);
         HostCsr AP;
-        transpose_host(Pm, R);
         spgemm_host(A, Pm, AP);
         spgemm_host(R, AP, An);
         AP = HostCsr();
         spgemm_host(C, Pm, Cn);
         transpose_host(Cn, Ctn);
       }
-      MlLevel &Nx = ctx->ml[l + 1];
       PhaseClock pc(ctx, ALFD_SETUP_ML_UPLOAD);
       RC(upload_level_part(ctx, Nx.A, An, nullptr, false));
       RC(upload_level_part(ctx, Nx.C, Cn, nullptr, false));
       RC(upload_level_part(ctx, Nx.Ct, Ctn, nullptr, false));
-      RC(upload_level_part(ctx, Nx.P, Pm, nullptr, true));
-      RC(upload_level_part(ctx, Nx.R, R, nullptr, true));
       if (l + 1 < nlev) {
-        A = std::move(An);
+        A = std::move(An);      // host copies of the new level: the next level's fallback product, aggregation levels
+        have_host_A = true;
         C = std::move(Cn);
         Ct = std::move(Ctn);
       }
       continue;
     }
     // ---- next level: Galerkin products of this rank's rows
+    if (l == 0) RC(fetch_A(ctx->mat[ALFD_A]));
     const std::vector<int32_t> &aggG = ctx->ml_agg[l];  // owned fine dof -> GLOBAL coarse id (or -1)
     const double *w = ctx->ml_wgt[l].empty() ? nullptr : ctx->ml_wgt[l].data();
     if (w && ctx->nranks > 1) return ctx->err = "weighted aggregates are single-rank for now", ALFD_E_UNSUPPORTED;
@@ -4278,6 +4475,7 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_SHORT_MIN_BLOCKS")) ctx->win_short_min_blocks = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_MAXW")) ctx->win_maxW = std::min(16384, std::max(256, std::atoi(e)));
   if (const char *e = std::getenv("ALFD_ML_REPLICATE")) ctx->ml_rep_threshold = std::atoll(e);
+  if (const char *e = std::getenv("ALFD_ML_GPU_GALERKIN")) ctx->ml_gpu_galerkin = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_LEVELS")) ctx->vi_levels = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_BATCH_MAJOR")) ctx->vs_enable = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_XCD")) ctx->vi_xcd = std::atoi(e);
@@ -4838,6 +5036,7 @@ int alfd_bench_spmv_format(alfd_ctx_t ctx, int slot, int32_t reps, int use_value
   CHECK_CTX();
   if (slot < 0 || slot >= ALFD_NSLOTS || !ctx->mat[slot].present) return ALFD_E_INVALID;
   const bool was_off = ctx->vi_off;
+  if (!use_value_index) RC(ensure_window_plan(ctx, ctx->mat[slot]));
   ctx->vi_off = !use_value_index;
   const int rc = alfd_bench_spmv(ctx, slot, reps, ms_per_launch, nullptr);
   ctx->vi_off = was_off;
@@ -4928,7 +5127,7 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   const DevCsr &m = ctx->mat[slot];
   std::memset(out, 0, sizeof(*out));
   out->lanes = m.L;
-  out->windowed = m.win ? 1 : 0;
+  out->windowed = (m.win || m.win_deferred) ? 1 : 0;
   out->value_indexed = (m.vi || (m.vs.on && ctx->vs_enable)) ? 1 : 0;
   out->batch_major = (m.vs.on && ctx->vs_enable) ? (m.vs.bricks ? 2 : 1) : 0;
   out->nnz = m.nnz;
@@ -5320,10 +5519,12 @@ int alfd_set_tunable(alfd_ctx_t ctx, const char *name, int value) {
   if (!ctx || !name) return ALFD_E_INVALID;
   if (std::strcmp(name, "value_index") == 0) {
     ctx->vi_off = value == 0;
+    if (value == 0) RC(ensure_window_plans(ctx));   // the general kernel needs the (deferred) window plans
     return ALFD_OK;
   }
   if (std::strcmp(name, "batch_major") == 0) {   // takes effect at the next alfd_set_matrix
     ctx->vs_enable = value != 0;
+    if (value == 0) RC(ensure_window_plans(ctx));
     return ALFD_OK;
   }
   if (std::strcmp(name, "batch_major_share") == 0) {   // 0: no template-shared batches (takes effect at the next alfd_set_matrix)

@@ -1420,4 +1420,142 @@ __global__ void scatter_add_kernel(int64_t n, const int32_t *__restrict__ idx, c
   if (i < n) out[idx[i]] = out[idx[i]] + x[i];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Sparse product C = A * P on the device, one 64-lane workgroup per output row (the Galerkin products of the multigrid
+// setup: A P, then P^T (A P), and C P).  Deterministic and equal bit for bit to the host / oracle definition: every
+// output entry (i, J) is ONE sequential fma chain over the entries k of row i of A in CSR order and the entries of row
+// col_k of P in CSR order, acc = fma(a_ik, p_kJ, acc) from 0; the row comes out sorted by column.
+//   pass 0 (symbolic): counts[i] = number of distinct columns of row i (LDS hash set of the candidates)
+//   pass 1 (numeric):  the same set, compacted and sorted in LDS (bitonic), then lane t owns output column t and walks
+//                      the row of A once, looking its column up in every P row it meets (wave-uniform control flow,
+//                      broadcast loads).
+// kSgTable slots per hash set, at most kSgMaxOut distinct columns per row (overflow[0] is set otherwise: the host falls
+// back to its own product).
+constexpr int kSgTable = 4096;
+constexpr int kSgMaxOut = 1024;
+__global__ __launch_bounds__(64) void spgemm_rows_kernel(int64_t nrows, const int64_t *__restrict__ arp,
+                                                         const int32_t *__restrict__ acol, const double *__restrict__ aval,
+                                                         const int64_t *__restrict__ prp, const int32_t *__restrict__ pcol,
+                                                         const double *__restrict__ pval, int pass,
+                                                         int32_t *__restrict__ counts, const int64_t *__restrict__ crp,
+                                                         int32_t *__restrict__ ccol, double *__restrict__ cval,
+                                                         int32_t *__restrict__ overflow) {
+  __shared__ int32_t table[kSgTable];
+  __shared__ int32_t keys[kSgMaxOut];
+  __shared__ int32_t cnt;
+  const int lane = threadIdx.x;
+  for (int64_t i = blockIdx.x; i < nrows; i += gridDim.x) {
+    const int64_t k0 = arp[i], k1 = arp[i + 1];
+    if (k0 == k1) {
+      if (pass == 0 && lane == 0) counts[i] = 0;
+      continue;
+    }
+    for (int s = lane; s < kSgTable; s += 64) table[s] = -1;
+    if (lane == 0) cnt = 0;
+    __syncthreads();
+    for (int64_t k = k0 + lane; k < k1; k += 64) {
+      const int64_t j = acol[k];
+      for (int64_t e = prp[j]; e < prp[j + 1]; ++e) {
+        const int32_t J = pcol[e];
+        uint32_t h = ((uint32_t)J * 2654435761u) >> 20;   // 12 bits
+        for (;;) {
+          const int32_t old = atomicCAS(&table[h], -1, J);
+          if (old == -1) {
+            atomicAdd(&cnt, 1);
+            break;
+          }
+          if (old == J) break;
+          h = (h + 1) & (kSgTable - 1);
+          if (*(volatile int32_t *)&cnt > kSgMaxOut) break;   // overflowing row: stop probing (reported below)
+        }
+      }
+    }
+    __syncthreads();
+    const int n = cnt;
+    if (n > kSgMaxOut) {
+      if (lane == 0) overflow[0] = 1;
+      if (pass == 0 && lane == 0) counts[i] = 0;
+      __syncthreads();
+      continue;
+    }
+    if (pass == 0) {
+      if (lane == 0) counts[i] = n;
+      __syncthreads();
+      continue;
+    }
+    // compact, pad to a power of two with INT_MAX, bitonic sort
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    __syncthreads();
+    if (lane == 0) cnt = 0;
+    __syncthreads();
+    for (int s = lane; s < kSgTable; s += 64) {
+      const int32_t J = table[s];
+      if (J != -1) keys[atomicAdd(&cnt, 1)] = J;
+    }
+    __syncthreads();
+    for (int s = n + lane; s < n2; s += 64) keys[s] = 0x7fffffff;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = lane; t < n2 / 2; t += 64) {
+          const int lo = 2 * t - (t & (stride - 1));
+          const int hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          const int32_t a = keys[lo], b = keys[hi];
+          if ((a > b) == up) {
+            keys[lo] = b;
+            keys[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+    // numeric: lane t owns output column keys[t]
+    const int64_t c0 = crp[i];
+    for (int t0 = 0; t0 < n; t0 += 64) {
+      const int t = t0 + lane;
+      const int32_t J = t < n ? keys[t] : -2;
+      double acc = 0.0;
+      for (int64_t k = k0; k < k1; ++k) {
+        const int64_t j = acol[k];
+        const double a = aval[k];
+        const int64_t e1 = prp[j + 1];
+        for (int64_t e = prp[j]; e < e1; ++e)
+          if (pcol[e] == J) acc = fma(a, pval[e], acc);
+      }
+      if (t < n) {
+        ccol[c0 + t] = J;
+        cval[c0 + t] = acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// flag[i] = 1 if row i of the CSR matrix has a column j with mark[j] >= 0 (rows of A that reach the interface patch)
+__global__ void rows_touching_kernel(int64_t nrows, const int64_t *__restrict__ rp, const int32_t *__restrict__ col,
+                                     const int32_t *__restrict__ mark, uint8_t *__restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (i >= nrows) return;
+  const int lane = threadIdx.x & 63;
+  int hit = 0;
+  for (int64_t k = rp[i] + lane; k < rp[i + 1]; k += 64) hit |= mark[col[k]] >= 0;
+  hit = __any(hit);
+  if (lane == 0) flag[i] = (uint8_t)(hit ? 1 : 0);
+}
+
+// copies the listed rows of a CSR matrix into a compact CSR whose row pointer orp the host computed
+__global__ void gather_rows_kernel(int64_t nlist, const int32_t *__restrict__ rows, const int64_t *__restrict__ rp,
+                                   const int32_t *__restrict__ col, const double *__restrict__ val,
+                                   const int64_t *__restrict__ orp, int32_t *__restrict__ ocol, double *__restrict__ oval) {
+  const int64_t q = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  if (q >= nlist) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t k0 = rp[rows[q]], len = rp[rows[q] + 1] - k0, o0 = orp[q];
+  for (int64_t k = lane; k < len; k += 64) {
+    ocol[o0 + k] = col[k0 + k];
+    oval[o0 + k] = val[k0 + k];
+  }
+}
+
 }  // namespace alfd

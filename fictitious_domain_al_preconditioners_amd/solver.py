@@ -558,8 +558,10 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_bloc
         if len(entry) > 2 and entry[2] is not None:      # (agg_local, n_coarse_global, coarse_offsets)
             ctx.set_aggregate_partition(level, entry[2])
     ctx.set_matrix(_abi.A, pb.mats["A"])
-    ctx.set_matrix(_abi.CT, pb.mats["Ct"])
+    # C before CT (and B before BT): an explicitly uploaded transpose is left alone, otherwise alfd_set_matrix(CT) would
+    # first derive C on the host (a single-threaded transpose + upload) only to see it replaced by the next call
     ctx.set_matrix(_abi.C_, pb.mats["C"])
+    ctx.set_matrix(_abi.CT, pb.mats["Ct"])
     if cfg.variant == _abi.RATIONAL:
         # rational branch (immersed_laplace.cc:585-631): K, Ct, immersed stiffness and mass
         ctx.set_matrix(_abi.M, pb.mats["M"])
@@ -579,8 +581,8 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_bloc
         ctx.set_matrix(_abi.M, pb.mats["M"])     # exact W^-1: CG on the immersed mass matrix
     ctx.set_diag(_abi.INVW, pb.inv_w_diag_squared())
     if "B" in pb.mats:
-        ctx.set_matrix(_abi.BT, pb.mats["Bt"])
         ctx.set_matrix(_abi.B, pb.mats["B"])
+        ctx.set_matrix(_abi.BT, pb.mats["Bt"])
         ctx.set_matrix(_abi.MP, pb.mats["Mp"])
         ctx.set_diag(_abi.MP_LUMPED_INV, pb.mp_lumped_inv())
     ctx.configure(cfg)
