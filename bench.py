@@ -81,10 +81,10 @@ def main():
     ap.add_argument("--ml-smooth-degree", type=int, default=None, help="default 3 (geometric) / 4 (aggregation)")
     ap.add_argument("--ml-smooth-degree-coarse", type=int, default=None,
                     help="smoother degree on levels >= 1 (default 5 with the geometric hierarchy, else the fine one)")
-    ap.add_argument("--ml-smooth-ratio", type=float, default=None, help="default 30 (geometric) / 256 (aggregation)")
+    ap.add_argument("--ml-smooth-ratio", type=float, default=None, help="default 40 (geometric) / 256 (aggregation)")
     ap.add_argument("--ml-coarse-degree", type=int, default=None)
-    ap.add_argument("--patch-degree", type=int, default=None, help="interface-patch Chebyshev degree (geometric hierarchy; 0 = off; default 20)")
-    ap.add_argument("--patch-ratio", type=float, default=None, help="default 400")
+    ap.add_argument("--patch-degree", type=int, default=None, help="interface-patch Chebyshev degree (geometric hierarchy; 0 = off; default 15)")
+    ap.add_argument("--patch-ratio", type=float, default=None, help="default 200")
     ap.add_argument("--coarse-direct", type=int, default=None, help="explicit coarsest inverse up to this many unknowns (default 1024)")
     ap.add_argument("--agg-a", type=int, default=2, help="nodes per aggregate edge (aggregation hierarchy)")
     ap.add_argument("--min-coarse", type=int, default=None,

@@ -138,15 +138,15 @@ def default_config(variant=AL_STOKES) -> Config:
 def bench_multilevel_settings(cfg: Config, geometric: bool = True) -> Config:
     """The multigrid settings of bench.py's default run, in one place so that the full-size property test and the
     mid-size oracle parity case cannot drift from the benchmark: geometric hierarchy (CSR prolongators) with
-    Chebyshev(3) / 30 smoothing on the fine level and degree 5 below, interface patch Chebyshev(20) / 400, explicit
+    Chebyshev(3) / 40 smoothing on the fine level and degree 5 below, interface patch Chebyshev(15) / 200, explicit
     coarsest inverse up to 1024 unknowns; inner CG cap 100 as in parameters_stokes_3d.prm:23.  geometric = False:
     the round-2 aggregation hierarchy (Chebyshev(4) / 256, Chebyshev(10) coarsest sweep), still used on several ranks."""
     cfg.inner_prec = PREC_MULTILEVEL
     cfg.inner.max_steps = 100
     cfg.ml_coarse_degree = 10
     if geometric:
-        cfg.ml_smooth_degree, cfg.ml_smooth_degree_coarse, cfg.ml_smooth_ratio = 3, 5, 30.0
-        cfg.ml_patch_degree, cfg.ml_patch_ratio, cfg.ml_coarse_direct = 20, 400.0, 1024
+        cfg.ml_smooth_degree, cfg.ml_smooth_degree_coarse, cfg.ml_smooth_ratio = 3, 5, 40.0
+        cfg.ml_patch_degree, cfg.ml_patch_ratio, cfg.ml_coarse_direct = 15, 200.0, 1024
     else:
         cfg.ml_smooth_degree, cfg.ml_smooth_degree_coarse, cfg.ml_smooth_ratio = 4, 0, 256.0
         cfg.ml_patch_degree, cfg.ml_coarse_direct = 0, 0

@@ -507,7 +507,7 @@ def test_properties_at_bench_scale(built):
     n = int(os.environ.get("ALFD_TEST_FULL_NCELLS", "74"))
     pb = problems.stokes3d_sphere(n, 4 if n >= 48 else 3)
     # bench.py's exact solver settings (one definition: _abi.bench_multilevel_settings): geometric hierarchy,
-    # Chebyshev(3)/30 + degree 5 below, interface patch 20/400, explicit coarsest inverse, inner cap 100
+    # Chebyshev(3)/40 + degree 5 below, interface patch 15/200, explicit coarsest inverse, inner cap 100
     # (parameters_stokes_3d.prm:23-24), prolongators down to BENCH_MIN_COARSE, 16x4x1 mesh bricks
     cfg = _abi.bench_multilevel_settings(_abi.default_config(_abi.AL_STOKES), geometric=True)
     ctx = solver.context_from_problem(pb, cfg, aggregates=problems.tensor_prolongators(pb.params, min_coarse=_abi.BENCH_MIN_COARSE),
