@@ -146,6 +146,21 @@ def case(name):
             cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
         else:
             cfg.w_inverse = _abi.W_MASS_INV_SQUARED
+    elif name == "laplace2d_operator_form_gmg_patch":
+        # operator form (AL term assembled into A, immersed_laplace.cc:653-705) + the round-3 multigrid: the patch
+        # operator is A[S,S] alone (aug_assembled), S still the rows the coupling matrix touches
+        pb = problems.laplace2d_circle(64, 4, surface_mass=True)
+        a_op, gamma_h, inv_w = problems.operator_form(pb)
+        pb.mats = dict(pb.mats, A=a_op)
+        pb.inv_w_override = inv_w
+        cfg = _abi.default_config(_abi.AL2)
+        cfg.gamma, cfg.aug_assembled = gamma_h, 1
+        cfg.outer = _abi.Control(_abi.CTRL_REDUCTION, 1000, 1e-10, 1e-12)
+        cfg.inner_prec = _abi.PREC_MULTILEVEL
+        cfg.ml_smooth_degree, cfg.ml_smooth_degree_coarse, cfg.ml_smooth_ratio = 2, 3, 20.0
+        cfg.ml_patch_degree, cfg.ml_patch_ratio, cfg.ml_coarse_direct = 6, 50.0, 1024
+        cfg.inner.max_steps = 100
+        return pb, cfg
     elif name in ("stokes3d_gmg_patch", "stokes3d_gmg", "laplace3d_gmg_patch", "elliptic_modified_gmg_patch"):
         # round 3: geometric multigrid through CSR prolongators (alfd_set_prolongator: Q2 -> Q1 embedding,
         # then (bi/tri)linear interpolation), the interface-patch corrections around the V-cycle and the
@@ -212,7 +227,7 @@ ALL_CASES = ["laplace2d_circle", "laplace2d_jacobi", "laplace3d_sphere", "stokes
              "laplace2d_operator_form_exact_w", "elliptic_modified_exact_w", "elliptic_ideal_exact_w",
              "elasticity_modified", "elasticity_modified_multilevel", "stokes3d_bench_settings",
              "stokes3d_fgmres95", "stokes3d_gmg_patch", "stokes3d_gmg", "laplace3d_gmg_patch",
-             "elliptic_modified_gmg_patch"]
+             "elliptic_modified_gmg_patch", "laplace2d_operator_form_gmg_patch"]
 
 
 def oracle_system(pb, cfg):

@@ -549,6 +549,44 @@ def test_properties_at_bench_scale(built):
     ctx.close()
 
 
+def test_prolongator_validation_and_single_rank_limits(built):
+    """alfd_set_prolongator refuses unsorted / out-of-range columns and a row count that does not match the level; the
+    round-3 preconditioner on a partitioned context is ALFD_E_UNSUPPORTED (stated limit, not a silent fallback); a
+    coarsest operator that is not positive definite fails the setup loudly."""
+    pb, cfg = cases.case("stokes3d_gmg_patch")
+    levels = cases.aggregates_of(pb, cfg)
+    P0 = levels[0][0]
+    ctx = solver.Context(0)
+    try:
+        bad = problems.Csr(P0.nrows, P0.ncols, P0.row_ptr.copy(), P0.col.copy(), P0.val.copy())
+        k = int(np.flatnonzero(np.diff(P0.row_ptr) >= 2)[0])
+        a = int(P0.row_ptr[k])
+        bad.col[a], bad.col[a + 1] = bad.col[a + 1], bad.col[a]              # descending inside a row
+        with pytest.raises(solver.AlfdError):
+            ctx.set_prolongator(0, bad)
+        bad.col[:] = P0.col
+        bad.col[a] = P0.ncols                                                  # out of range
+        with pytest.raises(solver.AlfdError):
+            ctx.set_prolongator(0, bad)
+        # wrong fine size: caught at setup
+        short = problems.Csr(P0.nrows - 3, P0.ncols, P0.row_ptr[:-3].copy(), P0.col[:int(P0.row_ptr[-4])].copy(),
+                             P0.val[:int(P0.row_ptr[-4])].copy())
+        with pytest.raises(solver.AlfdError):
+            solver.upload_problem(ctx, pb, cfg, [(short, levels[0][1])])
+        # an indefinite "prolongated" coarsest operator: P with a zero column -> singular Galerkin matrix
+        P1 = levels[1][0]
+        sing = problems.Csr(P1.nrows, P1.ncols, P1.row_ptr.copy(), P1.col.copy(), np.where(P1.col == 0, 0.0, P1.val))
+        with pytest.raises(solver.AlfdError, match="positive definite"):
+            solver.upload_problem(ctx, pb, _abi.Config.from_buffer_copy(cfg), [levels[0], (sing, levels[1][1])])
+        # the good hierarchy still sets up and solves on the same context afterwards
+        solver.upload_problem(ctx, pb, cfg, levels)
+        rhs = ctx.augment_rhs(cases.rhs_of(pb))
+        _, res = ctx.solve(rhs)
+        assert res.status == 0 and res.outer_iterations == 10
+    finally:
+        ctx.close()
+
+
 def test_row_block_hint_validation_and_stale_hint(built):
     """alfd_set_row_blocks refuses a prefix that does not start at 0 / is not monotone before copying anything with it;
     a hint given for a matrix of another size is dropped at the next upload of the slot (runs of the numbering take
