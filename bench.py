@@ -77,7 +77,7 @@ def main():
                     default=os.environ.get("ALFD_BENCH_PREC", "multilevel"))
     ap.add_argument("--hierarchy", choices=["geometric", "aggregation"], default=os.environ.get("ALFD_BENCH_HIERARCHY", "geometric"),
                     help="multigrid transfers: CSR prolongators (Q2 -> Q1 embedding, then trilinear interpolation; "
-                         "alfd_set_prolongator) or piecewise-constant aggregates (round 2; the only one on several ranks)")
+                         "alfd_set_prolongator) or piecewise-constant aggregates (round 2)")
     ap.add_argument("--ml-smooth-degree", type=int, default=None, help="default 3 (geometric) / 4 (aggregation)")
     ap.add_argument("--ml-smooth-degree-coarse", type=int, default=None,
                     help="smoother degree on levels >= 1 (default 5 with the geometric hierarchy, else the fine one)")
@@ -146,7 +146,7 @@ def main():
     cfg.cheb_degree = args.cheb_degree
     cfg.log_level = int(os.environ.get("ALFD_BENCH_LOG_LEVEL", "0"))
     aggregates = levels = None
-    geometric = args.hierarchy == "geometric" and world == 1      # CSR prolongators are single-rank for now
+    geometric = args.hierarchy == "geometric"      # several ranks: fine level partitioned, coarse levels + patch replicated
     if args.inner_prec == "multilevel":
         _abi.bench_multilevel_settings(cfg, geometric)
         for field, val in (("ml_smooth_degree", args.ml_smooth_degree), ("ml_smooth_degree_coarse", args.ml_smooth_degree_coarse),
@@ -174,6 +174,8 @@ def main():
     ta = time.time()
     if cfg.inner_prec == _abi.PREC_MULTILEVEL and geometric:
         levels = aggregates = problems.tensor_prolongators(pb.params, min_coarse=min_coarse)
+        if world > 1:       # level 0: this rank's rows + the coarse offsets by rank; the levels below whole (replicated)
+            aggregates = partition.local_prolongators(levels, pb.params, plan, rank)
         log(f"prolongators: levels {[lv[1] for lv in levels]} in {time.time()-ta:.1f} s")
     elif cfg.inner_prec == _abi.PREC_MULTILEVEL:
         levels = partition.partitioned_geometric_aggregates(pb.params, plan, a=args.agg_a, min_coarse=min_coarse)   # slab-respecting boxes

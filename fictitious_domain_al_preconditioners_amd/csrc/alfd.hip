@@ -41,6 +41,7 @@
 
 namespace alfd {
 
+
 // ------------------------------------------------------------------ helpers
 #define HIPC(call)                                                                          \
   do {                                                                                      \
@@ -152,6 +153,7 @@ struct MlLevel {
   // multi-rank: levels from alfd_ctx::ml_rep_level on are REPLICATED on every rank (global operators and
   // vectors, no halo exchanges); gP / gR connect two replicated levels, P / R above stay rank-local
   DevCsr gA, gC, gCt, gP, gR;
+  bool P_global_cols = false;   // P of this level addresses the replicated coarse vector by GLOBAL ids (CSR prolongators)
   int64_t gn = 0, gnpad = 0, g_maxpiece = 0;
   std::vector<int64_t> g_offs;  // rank offsets of this level's unknowns (size nranks + 1)
   double *gdinv = nullptr, *gr = nullptr, *gz = nullptr, *gt = nullptr, *gcd = nullptr, *gcres = nullptr,
@@ -205,6 +207,7 @@ struct alfd_ctx {
   int64_t n[ALFD_MAX_BLOCKS] = {0, 0, 0};        // local block lengths
   int64_t off[ALFD_MAX_BLOCKS + 1] = {0, 0, 0, 0};  // padded local offsets
   int64_t nmax = 0;                               // max padded block length
+  int64_t diag_cap = 0;                           // length of the dA / s_aug scratch vectors
   DevCsr mat[ALFD_NSLOTS + 1];
   double *diag[ALFD_NDIAGS] = {nullptr, nullptr};
   int64_t diag_n[ALFD_NDIAGS] = {0, 0};
@@ -243,9 +246,18 @@ struct alfd_ctx {
     double *dinv = nullptr, *rS = nullptr, *zS = nullptr, *uS = nullptr, *eS = nullptr, *cd = nullptr,
            *cres = nullptr, *ctmp = nullptr, *rr = nullptr;
     double lmax = 0;
+    // partitioned context: the patch is REPLICATED (Ass, Cs, Cts whole on every rank); S[] = this rank's rows
+    // (m_loc of them, patch ids soff[rank] ..), Cts_loc / Ctg = Ct[S_loc, :] / Ct[owned rows, :] over GLOBAL
+    // multiplier ids, As / Ats = this rank's rows of A[S, :] (halo on the fine vector) / A[:, S]
+    bool rep = false;
+    int64_t m_loc = 0, piece = 1, lam_piece = 1;
+    std::vector<int64_t> soff;
+    DevCsr Cts_loc, Ctg;
+    double *send = nullptr, *stage = nullptr, *lam_send = nullptr, *lam_stage = nullptr, *loc = nullptr;
   } patch;
   std::vector<MlLevel> ml;
   int ml_rep_level = -1;                      // first replicated level (multi-rank), -1: none
+  bool dots_replicated = false;               // reductions over REPLICATED vectors (every rank holds the whole vector): no exchange
   int64_t ml_rep_threshold = 300000;          // replicate levels with at most this many unknowns (ALFD_ML_REPLICATE)
   int ml_gpu_galerkin = 1;                    // Galerkin products of CSR-prolongator levels on the device (ALFD_ML_GPU_GALERKIN)
   double *g_w = nullptr, *g_tlam = nullptr;   // global W^-1 diagonal and multiplier work vector of the replicated levels
@@ -794,7 +806,7 @@ static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, do
 // count dots whose chunk partials sit at partial[j*pstride ..]; results land in
 // sc[out+j] (single rank) with optional PCG post-op.
 static int finish_dots(alfd_ctx *ctx, int64_t nb, int count, int out, int fin) {
-  if (ctx->nranks == 1) {
+  if (ctx->nranks == 1 || ctx->dots_replicated) {
     hipLaunchKernelGGL(dot_final_kernel, dim3(count), dim3(kBlock), 0, ctx->stream, ctx->partial, nb,
                        ctx->pstride, ctx->sc, out, fin);
     HIPC(hipGetLastError());
@@ -2870,6 +2882,12 @@ static int diag_plus(alfd_ctx *ctx, int slot_diag, int slot_rows, double g, int6
   return diag_plus_m(ctx, ctx->mat[slot_diag], ctx->mat[slot_rows], g, n, dinv);
 }
 static int diag_plus_m(alfd_ctx *ctx, const DevCsr &A, DevCsr &R, double g, int64_t n, double *dinv) {
+  if (pad_chunk(n) > ctx->diag_cap) {
+    // a replicated multigrid level may be longer than this rank's largest block (many ranks): grow the two scratch vectors
+    RC(ws_alloc_zero(ctx, &ctx->dA, pad_chunk(n)));
+    RC(ws_alloc_zero(ctx, &ctx->s_aug, pad_chunk(n)));
+    ctx->diag_cap = pad_chunk(n);
+  }
   HIPC(hipMemsetAsync(ctx->dA, 0, pad_chunk(n) * sizeof(double), ctx->stream));
   HIPC(hipMemsetAsync(ctx->s_aug, 0, pad_chunk(n) * sizeof(double), ctx->stream));
   const int grid = grid_for_rows(A.nrows, A.L);
@@ -2948,7 +2966,9 @@ static void free_levels(alfd_ctx *ctx) {
     for (DevCsr *m : {&L.A, &L.C, &L.Ct, &L.P, &L.R, &L.gA, &L.gC, &L.gCt, &L.gP, &L.gR}) csr_free(*m);
   ctx->ml.clear();
   csr_free(ctx->ml_inv);
-  for (DevCsr *m : {&ctx->patch.Ass, &ctx->patch.As, &ctx->patch.Ats, &ctx->patch.Cs, &ctx->patch.Cts}) csr_free(*m);
+  for (DevCsr *m : {&ctx->patch.Ass, &ctx->patch.As, &ctx->patch.Ats, &ctx->patch.Cs, &ctx->patch.Cts, &ctx->patch.Cts_loc,
+                    &ctx->patch.Ctg})
+    csr_free(*m);
   ctx->patch = alfd_ctx::Patch();   // its vectors belong to the setup workspace
   ctx->ml_rep_level = -1;
 }
@@ -3158,7 +3178,10 @@ static int level_cheb_rep(alfd_ctx *ctx, int l, int degree, double ratio, const 
 static int ml_cycle_rep(alfd_ctx *ctx, int l, const double *r, double *z) {
   const alfd_config &c = ctx->cfg;
   const int last = (int)ctx->ml.size() - 1;
-  if (l == last) return level_cheb_rep(ctx, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  if (l == last) {
+    if (ctx->ml_inv.present) return spmv_m(ctx, ctx->ml_inv, ALFD_T_SPMV_OTHER, r, z, 0);
+    return level_cheb_rep(ctx, l, c.ml_coarse_degree, c.ml_coarse_ratio, r, z);
+  }
   MlLevel &L = ctx->ml[l], &N = ctx->ml[l + 1];
   const int sdeg = l > 0 && c.ml_smooth_degree_coarse > 0 ? c.ml_smooth_degree_coarse : c.ml_smooth_degree;
   RC(level_cheb_rep(ctx, l, sdeg, c.ml_smooth_ratio, r, z));
@@ -3200,7 +3223,8 @@ static int ml_cycle(alfd_ctx *ctx, int l, const double *r, double *z) {
                             hipMemcpyDeviceToDevice, ctx->stream));
     }
     RC(ml_cycle_rep(ctx, l + 1, N.gr, N.gz));
-    RC(spmv_m(ctx, N.P, ALFD_T_SPMV_OTHER, N.gz + N.g_offs[ctx->rank], z, 1, 1.0));   // z += P e_c (my slice)
+    // z += P e_c: aggregates -> my slice of e_c; CSR prolongators address the replicated vector by global ids
+    RC(spmv_m(ctx, N.P, ALFD_T_SPMV_OTHER, N.P_global_cols ? N.gz : N.gz + N.g_offs[ctx->rank], z, 1, 1.0));
   } else {
     RC(ml_cycle(ctx, l + 1, N.r, N.z));
     RC(spmv_m(ctx, N.P, ALFD_T_SPMV_OTHER, N.z, z, 1, 1.0));                 // z += P e_c
@@ -3220,8 +3244,10 @@ static int patch_op(alfd_ctx *ctx, const double *x, double *y) {
   alfd_ctx::Patch &Q = ctx->patch;
   RC(spmv_m(ctx, Q.Ass, ALFD_T_SPMV_OTHER, x, y, 0));
   if (ctx->cfg.aug_assembled) return ALFD_OK;
-  RC(spmv_m(ctx, Q.Cs, ALFD_T_SPMV_OTHER, x, ctx->t_lam, 2, 0.0, ctx->diag[ALFD_INVW]));
-  return spmv_m(ctx, Q.Cts, ALFD_T_SPMV_OTHER, ctx->t_lam, y, 1, ctx->cfg.gamma);
+  double *t = Q.rep ? ctx->g_tlam : ctx->t_lam;                       // replicated patch: the whole multiplier space
+  const double *w = Q.rep ? ctx->g_w : ctx->diag[ALFD_INVW];
+  RC(spmv_m(ctx, Q.Cs, ALFD_T_SPMV_OTHER, x, t, 2, 0.0, w));
+  return spmv_m(ctx, Q.Cts, ALFD_T_SPMV_OTHER, t, y, 1, ctx->cfg.gamma);
 }
 
 // z = q(D^-1 Aug_SS) D^-1 r, q = Chebyshev polynomial of degree ml_patch_degree (zero start)
@@ -3246,9 +3272,57 @@ static int patch_cheb(alfd_ctx *ctx, const double *r, double *z) {
 
 // The multilevel inner preconditioner: the V-cycle, wrapped (ml_patch_degree > 0) into two corrections on the
 // interface patch:  z1 = E q E^T r;  z2 = z1 + V(r - Aug z1);  z = z2 + E q E^T (r - Aug z2)  -- symmetric.
+// device vector pieces (offs[p+1] - offs[p] doubles on rank p) -> the whole vector on every rank
+static int allgather_pieces(alfd_ctx *ctx, const double *mine, const std::vector<int64_t> &offs, int64_t piece, double *send,
+                            double *stage, double *whole) {
+  const int64_t n_me = offs[ctx->rank + 1] - offs[ctx->rank];
+  if (n_me > 0) HIPC(hipMemcpyAsync(send, mine, n_me * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  RC(comm_allgather(ctx, send, stage, (size_t)piece * sizeof(double)));
+  for (int p = 0; p < ctx->nranks; ++p) {
+    const int64_t np = offs[p + 1] - offs[p];
+    if (np > 0)
+      HIPC(hipMemcpyAsync(whole + offs[p], stage + (int64_t)p * piece, np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return ALFD_OK;
+}
+
+// ml_apply on a partitioned context: same arithmetic, the patch polynomial runs redundantly on every rank
+static int ml_apply_rep(alfd_ctx *ctx, const double *r, double *z) {
+  alfd_ctx::Patch &Q = ctx->patch;
+  const int64_t n0p = pad_chunk(ctx->n[0]);
+  const unsigned gm = (unsigned)std::max<int64_t>(1, (Q.m_loc + 255) / 256);
+  const bool pen = !ctx->cfg.aug_assembled;
+  const int last = ctx->nblocks - 1;
+  const int64_t s0 = Q.soff[ctx->rank];
+  if (Q.m_loc > 0) hipLaunchKernelGGL(gather_kernel, dim3(gm), dim3(256), 0, ctx->stream, Q.m_loc, Q.S, r, Q.loc);
+  RC(allgather_pieces(ctx, Q.loc, Q.soff, Q.piece, Q.send, Q.stage, Q.rS));
+  RC(patch_cheb(ctx, Q.rS, Q.zS));
+  VEC_LAUNCH(scale_copy_kernel, n0p, 16, 1.0, r, Q.rr);
+  RC(spmv_m(ctx, Q.Ats, ALFD_T_SPMV_OTHER, Q.zS, Q.rr, 1, -1.0));
+  if (pen) {
+    RC(spmv_m(ctx, Q.Cs, ALFD_T_SPMV_OTHER, Q.zS, ctx->g_tlam, 2, 0.0, ctx->g_w));
+    RC(spmv_m(ctx, Q.Ctg, ALFD_T_SPMV_OTHER, ctx->g_tlam, Q.rr, 1, -ctx->cfg.gamma));
+  }
+  RC(ml_cycle(ctx, 0, Q.rr, z));
+  if (Q.m_loc > 0) hipLaunchKernelGGL(scatter_add_kernel, dim3(gm), dim3(256), 0, ctx->stream, Q.m_loc, Q.S, Q.zS + s0, z);
+  RC(spmv_m(ctx, Q.As, ALFD_T_SPMV_OTHER, z, Q.loc, 0));                          // my rows of (A z) on S
+  if (pen) {
+    RC(spmv(ctx, ALFD_C, z, ctx->t_lam, 2, 0.0, ctx->diag[ALFD_INVW]));          // my multipliers of W^-1 C z
+    RC(allgather_pieces(ctx, ctx->t_lam, ctx->part[last], Q.lam_piece, Q.lam_send, Q.lam_stage, ctx->g_tlam));
+    RC(spmv_m(ctx, Q.Cts_loc, ALFD_T_SPMV_OTHER, ctx->g_tlam, Q.loc, 1, ctx->cfg.gamma));
+  }
+  RC(allgather_pieces(ctx, Q.loc, Q.soff, Q.piece, Q.send, Q.stage, Q.uS));
+  VEC_LAUNCH(sub_from_kernel, Q.mpad, 24, Q.rS, Q.uS);
+  RC(patch_cheb(ctx, Q.uS, Q.eS));
+  if (Q.m_loc > 0) hipLaunchKernelGGL(scatter_add_kernel, dim3(gm), dim3(256), 0, ctx->stream, Q.m_loc, Q.S, Q.eS + s0, z);
+  HIPC(hipGetLastError());
+  return ALFD_OK;
+}
+
 static int ml_apply(alfd_ctx *ctx, const double *r, double *z) {
   alfd_ctx::Patch &Q = ctx->patch;
   if (!Q.on) return ml_cycle(ctx, 0, r, z);
+  if (Q.rep) return ml_apply_rep(ctx, r, z);
   const int64_t n0p = pad_chunk(ctx->n[0]);
   const unsigned gm = (unsigned)((Q.m + 255) / 256);
   const bool pen = !ctx->cfg.aug_assembled;
@@ -3360,6 +3434,7 @@ static void extract_host(const HostCsr &A, const std::vector<int32_t> &rows, con
 }
 
 static int upload_level(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h);
+static int upload_level_part(alfd_ctx *ctx, DevCsr &dst, const HostCsr &h, const int64_t *col_offsets, bool local_only);
 static int level_op(alfd_ctx *ctx, int l, const double *x, double *y);
 
 // A CSR matrix in plain device arrays (intermediate products of the Galerkin setup)
@@ -3637,7 +3712,7 @@ static int coarse_inverse(alfd_ctx *ctx, const HostCsr &A, const HostCsr &C, con
       });
     for (auto &x : th) x.join();
   }
-  RC(upload_level(ctx, ctx->ml_inv, X));
+  RC(upload_level_part(ctx, ctx->ml_inv, X, nullptr, true));   // never partitioned: every rank that has it has it whole
   return ALFD_OK;
 }
 
@@ -3860,6 +3935,484 @@ static void aggregate_level(const HostCsr &A, int bs, double theta, int max_size
   n_coarse = (int64_t)nagg * bs;
 }
 
+// Rows of a row-partitioned CSR matrix (this rank holds the global rows [row_off[rank], row_off[rank + 1]) as `loc`,
+// any column space) for an arbitrary list of GLOBAL row ids: out gets one row per entry of `want`, in that order.
+// Collective (setup only): requests and answers travel through all-gathers, so every rank sees all of them.
+static int fetch_rows(alfd_ctx *ctx, const HostCsr &loc, const int64_t *row_off, const std::vector<int64_t> &want,
+                      HostCsr &out) {
+  const int P = ctx->nranks, me = ctx->rank;
+  std::vector<char> breq, bans;
+  std::vector<size_t> sreq, sans;
+  RC(allgather_bytes(ctx, want.data(), want.size() * sizeof(int64_t), breq, sreq));
+  std::vector<std::vector<int64_t>> req(P);
+  {
+    size_t pos = 0;
+    for (int p = 0; p < P; ++p) {
+      req[p].resize(sreq[p] / sizeof(int64_t));
+      std::memcpy(req[p].data(), breq.data() + pos, sreq[p]);
+      pos += sreq[p];
+    }
+  }
+  // my answers: for every requester, the rows I own in its request order: int64 len, int32 cols (padded to 8), double vals
+  std::vector<char> ans;
+  auto put = [&](const void *q, size_t n) { ans.insert(ans.end(), (const char *)q, (const char *)q + n); };
+  for (int p = 0; p < P; ++p)
+    for (int64_t g : req[p]) {
+      if (g < row_off[me] || g >= row_off[me + 1]) continue;
+      const int64_t i = g - row_off[me], k0 = loc.rp[i], len = loc.rp[i + 1] - k0;
+      put(&len, 8);
+      put(loc.col.data() + k0, (size_t)len * 4);
+      if (len & 1) {
+        const int32_t z = 0;
+        put(&z, 4);
+      }
+      put(loc.val.data() + k0, (size_t)len * 8);
+    }
+  RC(allgather_bytes(ctx, ans.data(), ans.size(), bans, sans));
+  out.nrows = (int64_t)want.size();
+  out.ncols = loc.ncols;
+  out.rp.assign(1, 0);
+  out.col.clear();
+  out.val.clear();
+  std::vector<size_t> base(P + 1, 0);
+  for (int o = 0; o < P; ++o) base[o + 1] = base[o] + sans[o];
+  // walk every owner's blob in the order it was written; keep what was meant for me, placed by request position
+  std::vector<std::pair<const char *, int64_t>> mine(want.size(), {nullptr, 0});
+  for (int o = 0; o < P; ++o) {
+    const char *q = bans.data() + base[o];
+    for (int p = 0; p < P; ++p)
+      for (size_t t = 0; t < req[p].size(); ++t) {
+        const int64_t g = req[p][t];
+        if (g < row_off[o] || g >= row_off[o + 1]) continue;
+        int64_t len;
+        std::memcpy(&len, q, 8);
+        if (p == me) mine[t] = {q + 8, len};
+        q += 8 + (size_t)((len + 1) / 2 * 2) * 4 + (size_t)len * 8;
+      }
+  }
+  for (size_t t = 0; t < want.size(); ++t) {
+    if (!mine[t].first) return ctx->err = "fetch_rows: a requested row has no owner", ALFD_E_COMM;
+    const int64_t len = mine[t].second;
+    const int32_t *c = (const int32_t *)mine[t].first;
+    const double *v = (const double *)(mine[t].first + (size_t)((len + 1) / 2 * 2) * 4);
+    out.col.insert(out.col.end(), c, c + len);
+    out.val.insert(out.val.end(), v, v + len);
+    out.rp.push_back((int64_t)out.col.size());
+  }
+  return ALFD_OK;
+}
+
+static int upload_raw(alfd_ctx *ctx, const HostCsr &h, DevRawCsr &d) {
+  d = DevRawCsr();
+  d.nrows = h.nrows;
+  d.ncols = h.ncols;
+  d.nnz = h.nnz();
+  HIPC(hipMalloc((void **)&d.rp, (h.nrows + 1) * sizeof(int64_t)));
+  HIPC(hipMalloc((void **)&d.col, std::max<int64_t>(d.nnz, 1) * sizeof(int32_t)));
+  HIPC(hipMalloc((void **)&d.val, std::max<int64_t>(d.nnz, 1) * sizeof(double)));
+  HIPC(hipMemcpyAsync(d.rp, h.rp.data(), (h.nrows + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  if (d.nnz) {
+    HIPC(hipMemcpyAsync(d.col, h.col.data(), d.nnz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipMemcpyAsync(d.val, h.val.data(), d.nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPC(hipStreamSynchronize(ctx->stream));
+  return ALFD_OK;
+}
+
+// out = A * Pm with the device kernel when it fits, else on the host (both in the canonical order)
+static int product(alfd_ctx *ctx, const HostCsr &A, const HostCsr &Pm, HostCsr &out) {
+  if (ctx->ml_gpu_galerkin && A.nnz() > 200000) {
+    DevRawCsr dA, dP, dC;
+    RC(upload_raw(ctx, A, dA));
+    RC(upload_raw(ctx, Pm, dP));
+    bool fits = false;
+    const int rc = dev_spgemm(ctx, A.nrows, dA.rp, dA.col, dA.val, dP.rp, dP.col, dP.val, Pm.ncols, dC, &fits);
+    dA.release();
+    dP.release();
+    if (rc != ALFD_OK) return rc;
+    if (fits) {
+      const int rc2 = download_raw(ctx, dC, out);
+      dC.release();
+      return rc2;
+    }
+  }
+  spgemm_host(A, Pm, out);
+  return ALFD_OK;
+}
+
+static int coarse_inverse(alfd_ctx *ctx, const HostCsr &A, const HostCsr &C, const HostCsr &Ct, const std::vector<double> &w);
+static int patch_setup_rep(alfd_ctx *ctx);
+
+// The interface patch of a partitioned context: S is split by row ownership, the patch operators are gathered whole on
+// every rank (they are small), the polynomial runs redundantly; see ml_apply_rep.
+static int patch_setup_rep(alfd_ctx *ctx) {
+  alfd_ctx::Patch &Q = ctx->patch;
+  const alfd_config &c = ctx->cfg;
+  const int P = ctx->nranks, rk = ctx->rank, last = ctx->nblocks - 1;
+  const std::vector<int64_t> &off0 = ctx->part[0], &offl = ctx->part[last];
+  DevCsr &dA = ctx->mat[ALFD_A], &dC = ctx->mat[ALFD_C], &dCt = ctx->mat[ALFD_CT];
+  const int64_t n_loc = ctx->n[0];
+  HostCsr Ct, C;
+  RC(download_csr(ctx, dCt, Ct));
+  RC(download_csr(ctx, dC, C));
+  std::vector<int32_t> S;
+  for (int64_t i = 0; i < n_loc; ++i)
+    if (Ct.rp[i + 1] > Ct.rp[i]) S.push_back((int32_t)i);
+  // global S: every rank's list of global row ids, in rank order
+  std::vector<int64_t> Sg(S.size());
+  for (size_t q = 0; q < S.size(); ++q) Sg[q] = off0[rk] + S[q];
+  std::vector<char> ball;
+  std::vector<size_t> sz;
+  RC(allgather_bytes(ctx, Sg.data(), Sg.size() * sizeof(int64_t), ball, sz));
+  Q.soff.assign(P + 1, 0);
+  for (int p = 0; p < P; ++p) Q.soff[p + 1] = Q.soff[p] + (int64_t)(sz[p] / sizeof(int64_t));
+  const int64_t m = Q.soff[P];
+  if (m == 0) return ALFD_OK;
+  std::vector<int64_t> Sall(m);
+  std::memcpy(Sall.data(), ball.data(), (size_t)m * sizeof(int64_t));     // ascending: rank order = global order
+  auto patch_id = [&](int64_t g) -> int32_t {
+    auto it = std::lower_bound(Sall.begin(), Sall.end(), g);
+    return it != Sall.end() && *it == g ? (int32_t)(it - Sall.begin()) : -1;
+  };
+  // patch ids over the LOCAL column spaces [owned | halo] of A and of C
+  auto make_pos = [&](const DevCsr &mtx, std::vector<int32_t> &pos) {
+    pos.assign((size_t)mtx.n_local_cols + mtx.halo_globals.size(), -1);
+    for (size_t q = 0; q < S.size(); ++q) pos[S[q]] = (int32_t)(Q.soff[rk] + (int64_t)q);
+    for (size_t h = 0; h < mtx.halo_globals.size(); ++h) pos[mtx.n_local_cols + h] = patch_id(mtx.halo_globals[h]);
+  };
+  std::vector<int32_t> posA, posC, Trows;
+  make_pos(dA, posA);
+  make_pos(dC, posC);
+  HostCsr A_patch, h, g;
+  RC(fetch_patch_rows(ctx, dA, posA, A_patch, Trows));
+  // replicated operators: my rows, then gathered in rank order
+  extract_host(A_patch, S, posA.data(), m, false, h);
+  RC(gather_csr(ctx, h, nullptr, m, g));
+  RC(upload_level_part(ctx, Q.Ass, g, nullptr, true));
+  std::vector<int32_t> lam_rows(C.nrows);
+  for (int64_t k = 0; k < C.nrows; ++k) lam_rows[k] = (int32_t)k;
+  extract_host(C, lam_rows, posC.data(), m, false, h);
+  RC(gather_csr(ctx, h, nullptr, m, g));
+  RC(upload_level_part(ctx, Q.Cs, g, nullptr, true));
+  // Ct rows over GLOBAL multiplier ids
+  std::vector<int32_t> lamg((size_t)dCt.n_local_cols + dCt.halo_globals.size());
+  for (int32_t j = 0; j < dCt.n_local_cols; ++j) lamg[j] = (int32_t)(offl[rk] + j);
+  for (size_t j = 0; j < dCt.halo_globals.size(); ++j) lamg[dCt.n_local_cols + j] = dCt.halo_globals[j];
+  HostCsr Ctg = Ct;
+  Ctg.ncols = offl.back();
+  for (int64_t i = 0; i < Ctg.nrows; ++i) {   // rows re-sorted by the global id (the local order puts halo ids last)
+    std::vector<std::pair<int32_t, double>> row;
+    for (int64_t k = Ct.rp[i]; k < Ct.rp[i + 1]; ++k) row.emplace_back(lamg[Ct.col[k]], Ct.val[k]);
+    std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (size_t k = 0; k < row.size(); ++k) Ctg.col[Ct.rp[i] + k] = row[k].first, Ctg.val[Ct.rp[i] + k] = row[k].second;
+  }
+  extract_host(Ctg, S, nullptr, Ctg.ncols, false, h);
+  RC(upload_level_part(ctx, Q.Cts_loc, h, nullptr, true));
+  RC(gather_csr(ctx, h, nullptr, Ctg.ncols, g));
+  RC(upload_level_part(ctx, Q.Cts, g, nullptr, true));
+  RC(upload_level_part(ctx, Q.Ctg, Ctg, nullptr, true));
+  Q.Ass.rep = Q.Cs.rep = Q.Cts.rep = true;
+  // my rows of A[:, S] (patch ids, local-only) and of A[S, :] (global fine ids, halo on the fine vector)
+  extract_host(A_patch, Trows, posA.data(), m, true, h);
+  RC(upload_level_part(ctx, Q.Ats, h, nullptr, true));
+  extract_host(A_patch, S, nullptr, A_patch.ncols, false, h);
+  for (size_t k = 0; k < h.col.size(); ++k)
+    h.col[k] = (int32_t)(h.col[k] < dA.n_local_cols ? off0[rk] + h.col[k] : dA.halo_globals[h.col[k] - dA.n_local_cols]);
+  h.ncols = off0.back();
+  RC(upload_level_part(ctx, Q.As, h, off0.data(), false));
+  Q.m = m;
+  Q.mpad = pad_chunk(m);
+  Q.m_loc = (int64_t)S.size();
+  for (int p = 0; p < P; ++p) {
+    Q.piece = std::max(Q.piece, Q.soff[p + 1] - Q.soff[p]);
+    Q.lam_piece = std::max(Q.lam_piece, offl[p + 1] - offl[p]);
+  }
+  void *q = nullptr;
+  HIPC(hipMalloc(&q, std::max<int64_t>(Q.m_loc, 1) * sizeof(int32_t)));
+  ctx->ws_allocs.push_back(q);
+  Q.S = static_cast<int32_t *>(q);
+  if (Q.m_loc) HIPC(hipMemcpyAsync(Q.S, S.data(), Q.m_loc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  for (double **v : {&Q.dinv, &Q.rS, &Q.zS, &Q.uS, &Q.eS, &Q.cd, &Q.cres, &Q.ctmp}) RC(ws_alloc_zero(ctx, v, Q.mpad));
+  RC(ws_alloc_zero(ctx, &Q.rr, pad_chunk(n_loc)));
+  RC(ws_alloc_zero(ctx, &Q.loc, pad_chunk(std::max<int64_t>(Q.m_loc, 1))));
+  RC(ws_alloc_zero(ctx, &Q.send, Q.piece));
+  RC(ws_alloc_zero(ctx, &Q.stage, Q.piece * P));
+  RC(ws_alloc_zero(ctx, &Q.lam_send, Q.lam_piece));
+  RC(ws_alloc_zero(ctx, &Q.lam_stage, Q.lam_piece * P));
+  Q.rep = true;
+  // 1 / diag(Aug) on S: my entries, gathered
+  const unsigned gm = (unsigned)std::max<int64_t>(1, (Q.m_loc + 255) / 256);
+  if (Q.m_loc) hipLaunchKernelGGL(gather_kernel, dim3(gm), dim3(256), 0, ctx->stream, Q.m_loc, Q.S, ctx->dinv_aug, Q.loc);
+  RC(allgather_pieces(ctx, Q.loc, Q.soff, Q.piece, Q.send, Q.stage, Q.dinv));
+  // lambda_max(D^-1 Aug_SS) on the replicated patch: plain reductions, the same on every rank
+  ctx->dots_replicated = true;
+  double *v = Q.rS, *wv = Q.zS;
+  hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, m, (int64_t)0, v);
+  double lam = 0;
+  int rc = ALFD_OK;
+  for (int it = 0; it < c.cheb_power_its && rc == ALFD_OK; ++it) {
+    auto step = [&]() -> int {
+      RC(dot_async(ctx, Q.mpad, v, v, S_TMP));
+      RC(read_scalars(ctx, S_TMP, 1));
+      VEC_LAUNCH(scale_kernel, Q.mpad, 16, (const double *)nullptr, 0, 0, 1.0 / std::sqrt(ctx->sc_host[S_TMP]), v);
+      RC(patch_op(ctx, v, wv));
+      VEC_LAUNCH(pmul_scale_kernel, Q.mpad, 24, 1.0, Q.dinv, wv, wv);
+      RC(dot_async(ctx, Q.mpad, wv, wv, S_TMP));
+      RC(read_scalars(ctx, S_TMP, 1));
+      lam = std::sqrt(ctx->sc_host[S_TMP]);
+      std::swap(v, wv);
+      return ALFD_OK;
+    };
+    rc = step();
+  }
+  ctx->dots_replicated = false;
+  if (rc != ALFD_OK) return rc;
+  Q.lmax = lam * c.cheb_safety;
+  HIPC(hipMemsetAsync(Q.rS, 0, Q.mpad * sizeof(double), ctx->stream));
+  HIPC(hipMemsetAsync(Q.zS, 0, Q.mpad * sizeof(double), ctx->stream));
+  HIPC(hipStreamSynchronize(ctx->stream));
+  Q.on = true;
+  return ALFD_OK;
+}
+
+// ALFD_PREC_MULTILEVEL through CSR prolongators on a ROW-PARTITIONED context (round 3): the fine level stays
+// partitioned, every level below it -- and the interface patch -- is REPLICATED on all ranks.  Level 0: this rank holds
+// the prolongator rows of its own fine unknowns (global coarse ids) and alfd_set_aggregate_partition(0, ...) names the
+// rank that forms each coarse row; levels >= 1: the whole prolongator on every rank.  The hierarchy is the single-rank
+// one bit for bit: a coarse row's Galerkin chain and restriction sum run over its fine rows in GLOBAL order, remote
+// prolongator / A P rows are fetched from their owners (fetch_rows), finished rows are all-gathered.  Only the level-0
+// reductions differ from a single-rank run (rank-ordered sums, as on every partitioned path).
+static int ml_setup_rep_prolongators(alfd_ctx *ctx, int nlev) {
+  const alfd_config &c = ctx->cfg;
+  const int P = ctx->nranks, rk = ctx->rank, last = ctx->nblocks - 1;
+  for (int l = 0; l < nlev; ++l)
+    if (ctx->ml_P[l].rp.empty())
+      return ctx->err = "partitioned context: CSR prolongators and aggregates cannot be mixed", ALFD_E_UNSUPPORTED;
+  const std::vector<int64_t> &off0 = ctx->part[0], &coff = ctx->ml_coff[0];
+  const HostCsr &P0 = ctx->ml_P[0];
+  const int64_t n_loc = ctx->n[0], n1 = P0.ncols;
+  if ((int)coff.size() != P + 1 || coff.back() != n1 || P0.nrows != n_loc)
+    return ctx->err = "partitioned CSR prolongator: level 0 needs this rank's rows and alfd_set_aggregate_partition(0, coarse offsets)",
+           ALFD_E_INVALID;
+  for (int l = 1; l < nlev; ++l)
+    if (ctx->ml_P[l].nrows != ctx->ml_P[l - 1].ncols)
+      return ctx->err = "partitioned CSR prolongator: levels >= 1 must be given whole on every rank", ALFD_E_INVALID;
+  free_levels(ctx);
+  ctx->ml.assign(nlev + 1, MlLevel());
+  // ---- level 0 (partitioned): vectors only, operators are the slots
+  {
+    MlLevel &L = ctx->ml[0];
+    L.n = n_loc;
+    L.npad = pad_chunk(n_loc);
+    for (double **v : {&L.r, &L.z, &L.t, &L.cd, &L.cres, &L.ctmp}) RC(ws_alloc_zero(ctx, v, L.npad));
+    L.dinv = ctx->dinv_aug;
+    L.lmax = ctx->lam_max[OP_AUG];
+  }
+  HostCsr A1, C1, Ct1;
+  {
+    PhaseClock pc(ctx, ALFD_SETUP_ML_GALERKIN);
+    // A's rows in its LOCAL column space [owned | halo]: the prolongator rows in that order
+    DevCsr &dA = ctx->mat[ALFD_A], &dC = ctx->mat[ALFD_C];
+    auto perm_rows = [&](const DevCsr &m, HostCsr &Pperm, std::vector<int64_t> &colg) -> int {
+      std::vector<int64_t> want(m.halo_globals.begin(), m.halo_globals.end());
+      HostCsr halo;
+      RC(fetch_rows(ctx, P0, off0.data(), want, halo));
+      Pperm = P0;
+      Pperm.nrows = P0.nrows + halo.nrows;
+      for (int64_t i = 0; i < halo.nrows; ++i) Pperm.rp.push_back(Pperm.rp.back() + (halo.rp[i + 1] - halo.rp[i]));
+      Pperm.col.insert(Pperm.col.end(), halo.col.begin(), halo.col.end());
+      Pperm.val.insert(Pperm.val.end(), halo.val.begin(), halo.val.end());
+      colg.resize(Pperm.nrows);
+      for (int64_t q = 0; q < P0.nrows; ++q) colg[q] = off0[rk] + q;
+      for (size_t q = 0; q < want.size(); ++q) colg[P0.nrows + q] = want[q];
+      return ALFD_OK;
+    };
+    HostCsr PpA, PpC, AP_loc, AP_halo, CP_loc;
+    std::vector<int64_t> colgA, colgC;
+    RC(perm_rows(dA, PpA, colgA));
+    {   // A_r * P on the device, fetched (its rows are served to the neighbours below)
+      DevRawCsr dP, dAP;
+      RC(upload_raw(ctx, PpA, dP));
+      bool fits = false;
+      RC(dev_spgemm(ctx, dA.nrows, dA.rp, dA.col, dA.val, dP.rp, dP.col, dP.val, n1, dAP, &fits));
+      dP.release();
+      if (!fits) return ctx->err = "partitioned Galerkin product: a row exceeds the device kernel's column set", ALFD_E_UNSUPPORTED;
+      RC(download_raw(ctx, dAP, AP_loc));
+      dAP.release();
+    }
+    {
+      std::vector<int64_t> want(dA.halo_globals.begin(), dA.halo_globals.end());
+      RC(fetch_rows(ctx, AP_loc, off0.data(), want, AP_halo));
+    }
+    // R_owned: one row per owned coarse unknown, entries over the local fine space [owned | halo] in GLOBAL fine order
+    const int64_t c0 = coff[rk], nc_loc = coff[rk + 1] - c0;
+    HostCsr Rl, APp;
+    {
+      std::vector<int64_t> cnt(nc_loc + 1, 0);
+      for (int64_t q = 0; q < PpA.nrows; ++q)
+        for (int64_t k = PpA.rp[q]; k < PpA.rp[q + 1]; ++k) {
+          const int64_t I = PpA.col[k];
+          if (I >= c0 && I < c0 + nc_loc) cnt[I - c0 + 1]++;
+        }
+      for (int64_t I = 0; I < nc_loc; ++I) cnt[I + 1] += cnt[I];
+      std::vector<std::pair<int64_t, std::pair<int32_t, double>>> ent(cnt[nc_loc]);   // (global fine id, (local index, value))
+      std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+      for (int64_t q = 0; q < PpA.nrows; ++q)
+        for (int64_t k = PpA.rp[q]; k < PpA.rp[q + 1]; ++k) {
+          const int64_t I = PpA.col[k];
+          if (I >= c0 && I < c0 + nc_loc) ent[cur[I - c0]++] = {colgA[q], {(int32_t)q, PpA.val[k]}};
+        }
+      Rl.nrows = nc_loc;
+      Rl.ncols = PpA.nrows;
+      Rl.rp = cnt;
+      Rl.col.resize(ent.size());
+      Rl.val.resize(ent.size());
+      for (int64_t I = 0; I < nc_loc; ++I) {
+        std::sort(ent.begin() + cnt[I], ent.begin() + cnt[I + 1], [](const auto &a, const auto &b) { return a.first < b.first; });
+        for (int64_t k = cnt[I]; k < cnt[I + 1]; ++k) Rl.col[k] = ent[k].second.first, Rl.val[k] = ent[k].second.second;
+      }
+      APp = AP_loc;
+      APp.nrows = AP_loc.nrows + AP_halo.nrows;
+      for (int64_t i = 0; i < AP_halo.nrows; ++i) APp.rp.push_back(APp.rp.back() + (AP_halo.rp[i + 1] - AP_halo.rp[i]));
+      APp.col.insert(APp.col.end(), AP_halo.col.begin(), AP_halo.col.end());
+      APp.val.insert(APp.val.end(), AP_halo.val.begin(), AP_halo.val.end());
+    }
+    {
+      // every prolongator entry must have been seen by the rank that forms its coarse row: the fine rows in the support
+      // of an owned coarse unknown have to lie in this rank's rows or in A's halo (coarse partition aligned with the fine one)
+      int64_t cnt2[2] = {(int64_t)Rl.col.size(), P0.nnz()};
+      std::vector<char> ball;
+      std::vector<size_t> sz;
+      RC(allgather_bytes(ctx, cnt2, sizeof(cnt2), ball, sz));
+      int64_t seen = 0, total = 0;
+      for (int p = 0; p < P; ++p) {
+        int64_t v[2];
+        std::memcpy(v, ball.data() + (size_t)p * sizeof(cnt2), sizeof(cnt2));
+        seen += v[0];
+        total += v[1];
+      }
+      if (seen != total)
+        return ctx->err = "partitioned CSR prolongator: a coarse unknown's fine support leaves its rank's rows + halo of A "
+                          "(alfd_set_aggregate_partition must follow the fine partition)", ALFD_E_INVALID;
+    }
+    HostCsr A1_loc;
+    RC(product(ctx, Rl, APp, A1_loc));
+    RC(gather_csr(ctx, A1_loc, nullptr, n1, A1));
+    // C_1 = C P: rows of the owned multipliers, then gathered
+    RC(perm_rows(dC, PpC, colgC));
+    {
+      HostCsr Cl;
+      RC(download_csr(ctx, dC, Cl));
+      Cl.ncols = PpC.nrows;
+      RC(product(ctx, Cl, PpC, CP_loc));
+    }
+    RC(gather_csr(ctx, CP_loc, nullptr, n1, C1));
+    transpose_host(C1, Ct1);
+    // the partitioned transfer pair of level 0 <-> 1: R rows of the owned coarse unknowns (global fine columns, halo on
+    // the fine vector), P rows of the owned fine unknowns addressing the replicated coarse vector
+    HostCsr Rg = Rl;
+    Rg.ncols = off0.back();
+    for (size_t k = 0; k < Rg.col.size(); ++k) Rg.col[k] = (int32_t)colgA[Rl.col[k]];
+    MlLevel &N = ctx->ml[1];
+    PhaseClock pu(ctx, ALFD_SETUP_ML_UPLOAD);
+    RC(upload_level_part(ctx, N.R, Rg, off0.data(), false));
+    RC(upload_level_part(ctx, N.P, P0, nullptr, true));
+    N.P_global_cols = true;
+  }
+  // ---- replicated levels 1 .. nlev
+  const int64_t lam_global = ctx->part[last].back(), lam_pad = pad_chunk(lam_global);
+  RC(ws_alloc_zero(ctx, &ctx->g_w, lam_pad));
+  RC(ws_alloc_zero(ctx, &ctx->g_tlam, lam_pad));
+  RC(gather_vec(ctx, ctx->diag[ALFD_INVW], ctx->n[last], ctx->g_w));
+  ctx->ml_rep_level = 1;
+  HostCsr A = std::move(A1), C = std::move(C1), Ct = std::move(Ct1), An, Cn, Ctn, R;
+  for (int l = 1; l <= nlev; ++l) {
+    MlLevel &L = ctx->ml[l];
+    L.gn = A.nrows;
+    L.gnpad = pad_chunk(L.gn);
+    L.g_offs.assign(P + 1, 0);
+    if (l == 1) L.g_offs = coff;
+    else for (int p = 0; p <= P; ++p) L.g_offs[p] = L.gn * p / P;      // no partitioned piece below level 1
+    L.n = l == 1 ? coff[rk + 1] - coff[rk] : 0;
+    L.npad = pad_chunk(std::max<int64_t>(L.n, 1));
+    for (double **v : {&L.r, &L.z}) RC(ws_alloc_zero(ctx, v, L.npad));
+    {
+      PhaseClock pu(ctx, ALFD_SETUP_ML_UPLOAD);
+      RC(upload_level_part(ctx, L.gA, A, nullptr, true));
+      RC(upload_level_part(ctx, L.gC, C, nullptr, true));
+      RC(upload_level_part(ctx, L.gCt, Ct, nullptr, true));
+      L.gA.rep = L.gC.rep = L.gCt.rep = true;
+    }
+    for (double **v : {&L.gdinv, &L.gr, &L.gz, &L.gt, &L.gcd, &L.gcres, &L.gctmp}) RC(ws_alloc_zero(ctx, v, L.gnpad));
+    {
+      // diagonal and lambda_max on the replicated operator: plain (single-rank) reductions, the same on every rank
+      PhaseClock pl(ctx, ALFD_SETUP_ML_LAMBDA);
+      ctx->dots_replicated = true;
+      double *w_save = ctx->diag[ALFD_INVW];
+      ctx->diag[ALFD_INVW] = ctx->g_w;        // diag_plus_m reads the weight through the slot
+      const int rc = diag_plus_m(ctx, L.gA, L.gCt, c.aug_assembled ? 0.0 : c.gamma, L.gn, L.gdinv);
+      ctx->diag[ALFD_INVW] = w_save;
+      if (rc != ALFD_OK) return ctx->dots_replicated = false, rc;
+      double *v = L.gt, *wv = L.gr;
+      hipLaunchKernelGGL(hash_vector_kernel, dim3((unsigned)((L.gn + 255) / 256)), dim3(256), 0, ctx->stream, L.gn, (int64_t)0, v);
+      double lam = 0;
+      for (int it = 0; it < c.cheb_power_its; ++it) {
+        RC(dot_async(ctx, L.gnpad, v, v, S_TMP));
+        RC(read_scalars(ctx, S_TMP, 1));
+        VEC_LAUNCH(scale_kernel, L.gnpad, 16, (const double *)nullptr, 0, 0, 1.0 / std::sqrt(ctx->sc_host[S_TMP]), v);
+        RC(level_op_rep(ctx, l, v, wv));
+        VEC_LAUNCH(pmul_scale_kernel, L.gnpad, 24, 1.0, L.gdinv, wv, wv);
+        RC(dot_async(ctx, L.gnpad, wv, wv, S_TMP));
+        RC(read_scalars(ctx, S_TMP, 1));
+        lam = std::sqrt(ctx->sc_host[S_TMP]);
+        std::swap(v, wv);
+      }
+      ctx->dots_replicated = false;
+      L.lmax = lam * c.cheb_safety;
+      HIPC(hipMemsetAsync(L.gt, 0, L.gnpad * sizeof(double), ctx->stream));
+      HIPC(hipMemsetAsync(L.gr, 0, L.gnpad * sizeof(double), ctx->stream));
+    }
+    if (l == 1) {
+      for (int p = 0; p < P; ++p) L.g_maxpiece = std::max(L.g_maxpiece, coff[p + 1] - coff[p]);
+      L.g_maxpiece = std::max<int64_t>(L.g_maxpiece, 1);
+      RC(ws_alloc_zero(ctx, &L.g_send, L.g_maxpiece));
+      RC(ws_alloc_zero(ctx, &L.g_stage, L.g_maxpiece * P));
+    }
+    if (l == nlev) break;
+    const HostCsr &Pm = ctx->ml_P[l];
+    {
+      PhaseClock pg(ctx, ALFD_SETUP_ML_GALERKIN);
+      HostCsr AP;
+      transpose_host(Pm, R);
+      RC(product(ctx, A, Pm, AP));
+      RC(product(ctx, R, AP, An));
+      RC(product(ctx, C, Pm, Cn));
+      transpose_host(Cn, Ctn);
+    }
+    MlLevel &N = ctx->ml[l + 1];
+    PhaseClock pu(ctx, ALFD_SETUP_ML_UPLOAD);
+    RC(upload_level_part(ctx, N.gP, Pm, nullptr, true));
+    RC(upload_level_part(ctx, N.gR, R, nullptr, true));
+    N.gP.rep = N.gR.rep = true;
+    A = std::move(An);
+    C = std::move(Cn);
+    Ct = std::move(Ctn);
+  }
+  if (c.ml_coarse_direct > 0 && ctx->ml[nlev].gn > 0 && ctx->ml[nlev].gn <= c.ml_coarse_direct) {
+    PhaseClock pc(ctx, ALFD_SETUP_ML_COARSE);
+    std::vector<double> w(lam_global);
+    HIPC(hipMemcpyAsync(w.data(), ctx->g_w, w.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    RC(coarse_inverse(ctx, A, C, Ct, w));
+    ctx->ml_inv.rep = true;
+  }
+  if (c.ml_patch_degree > 0) {
+    PhaseClock pc(ctx, ALFD_SETUP_ML_PATCH);
+    RC(patch_setup_rep(ctx));
+  }
+  return ALFD_OK;
+}
+
 static int ml_setup(alfd_ctx *ctx) {
   const alfd_config &c = ctx->cfg;
   if (c.ml_smooth_degree < 1 || c.ml_coarse_degree < 1 || !(c.ml_smooth_ratio > 1.0) || !(c.ml_coarse_ratio > 1.0))
@@ -3872,8 +4425,9 @@ static int ml_setup(alfd_ctx *ctx) {
   }
   if (nlev == 0)
     return ctx->err = "alfd_set_aggregates / alfd_set_prolongator must precede alfd_setup for ALFD_PREC_MULTILEVEL", ALFD_E_NOT_SETUP;
-  if (ctx->nranks > 1 && (any_P || c.ml_patch_degree > 0 || c.ml_coarse_direct > 0))
-    return ctx->err = "CSR prolongators, the interface patch and the direct coarsest solve are single-rank for now", ALFD_E_UNSUPPORTED;
+  if (ctx->nranks > 1 && any_P) return ml_setup_rep_prolongators(ctx, nlev);
+  if (ctx->nranks > 1 && (c.ml_patch_degree > 0 || c.ml_coarse_direct > 0))
+    return ctx->err = "partitioned context: the interface patch and the direct coarsest solve need CSR prolongators", ALFD_E_UNSUPPORTED;
   if (c.ml_patch_degree > 0 && !(c.ml_patch_ratio > 1.0)) return ctx->err = "bad ml_patch_ratio", ALFD_E_INVALID;
   const int rk = ctx->rank, last = ctx->nblocks - 1;
   // rank offsets of every level's unknowns: level 0 = block 0, level l+1 = ml_coff[l]
@@ -4215,6 +4769,7 @@ static int setup(alfd_ctx *ctx) {
   RC(ws_alloc_zero(ctx, &ctx->dinv_aug, n0p));
   RC(ws_alloc_zero(ctx, &ctx->dA, ctx->nmax));
   RC(ws_alloc_zero(ctx, &ctx->s_aug, ctx->nmax));
+  ctx->diag_cap = ctx->nmax;
   RC(ws_alloc_zero(ctx, &ctx->w_r, wm));
   RC(ws_alloc_zero(ctx, &ctx->w_z, wm));
   RC(ws_alloc_zero(ctx, &ctx->w_p, wm));

@@ -127,3 +127,28 @@ def local_aggregates(levels, rank: int):
     for agg, n_coarse, coff, foff in levels:
         out.append((agg[int(foff[rank]):int(foff[rank + 1])], n_coarse, coff))
     return out
+
+
+def local_prolongators(levels, params: dict, plan: SlabPlan, rank: int):
+    """Per-rank view of problems.tensor_prolongators(...) for a slab-partitioned context (Context.set_prolongator +
+    set_aggregate_partition): level 0 -> this rank's rows of P and the coarse offsets that name, for every coarse unknown,
+    the rank owning the fine node it sits on (so that its fine support lies in that rank's rows + halo of A); levels >= 1
+    whole (they are replicated).  Returns [(Csr, n_coarse, coarse_offsets or None), ...]."""
+    from .problems import Csr
+    dim, ncomp, degree = params["dim"], params["ncomp"], params["degree"]
+    nf = degree * params["n_cells"]                              # cells of the fine nodal grid
+    nc = params["n_cells"] if degree > 1 else (params["n_cells"] + 1) // 2
+    plane_f = (nf + 1) ** (dim - 1)
+    zf = np.asarray(plan.node_offsets_u, np.int64) // plane_f   # first fine plane of every slab (world + 1)
+    # interior coarse planes k = 1 .. nc - 1 sit on fine plane (k * nf) // nc; interior coarse nodes per plane: (nc - 1)^(dim-1)
+    k = np.arange(1, nc)
+    owner = np.searchsorted(zf, (k * nf) // nc, side="right") - 1
+    per_plane = (nc - 1) ** (dim - 1) * ncomp
+    coff = np.array([int(np.sum(owner < r)) * per_plane for r in range(plan.world + 1)], np.int64)
+    P0, n1 = levels[0][0], levels[0][1]
+    assert coff[-1] == n1, (coff, n1)
+    r0, r1 = int(plan.offsets[0][rank]), int(plan.offsets[0][rank + 1])
+    out = [(P0.slice_rows(r0, r1), n1, coff)]
+    for P, n in levels[1:]:
+        out.append((P, n, None))
+    return out

@@ -553,6 +553,8 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_bloc
         agg, nc = entry[0], entry[1]
         if hasattr(agg, "row_ptr"):                       # a CSR prolongator (problems.tensor_prolongators)
             ctx.set_prolongator(level, agg)
+            if len(entry) > 2 and entry[2] is not None:   # partitioned context: coarse offsets by rank (partition.local_prolongators)
+                ctx.set_aggregate_partition(level, entry[2])
             continue
         ctx.set_aggregates(level, agg, nc)
         if len(entry) > 2 and entry[2] is not None:      # (agg_local, n_coarse_global, coarse_offsets)

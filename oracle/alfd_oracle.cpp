@@ -1691,10 +1691,10 @@ static int build(const orc_problem *op, const alfd_config *cfg, orc::Problem &P)
       m.col = op->ml_prolong[l].col;
       m.val = op->ml_prolong[l].val;
       P.ml_nc[l] = m.ncols;
-      if (op->nranks_emulated > 1) return ALFD_E_UNSUPPORTED;
+      // emulated ranks: the library keeps levels >= 1 and the patch REPLICATED and builds them partition-independently
+      // (ml_setup_rep_prolongators), so nothing below level 0 depends on the partition -- plain reductions there
     }
   }
-  if (cfg->ml_patch_degree > 0 && op->nranks_emulated > 1) return ALFD_E_UNSUPPORTED;
   if (cfg->inner_prec == ALFD_PREC_MULTILEVEL && P.ml_nlev < 1) return ALFD_E_NOT_SETUP;
   P.pt.nranks = op->nranks_emulated > 1 ? op->nranks_emulated : 1;
   if (P.pt.nranks > 1) {

@@ -19,7 +19,8 @@ def main():
     import cases
     from fictitious_domain_al_preconditioners_amd import _abi, partition, problems, solver
     multilevel = len(sys.argv) > 1 and sys.argv[1] == "multilevel"
-    n, ref = 8, 0
+    geometric = len(sys.argv) > 1 and sys.argv[1] == "geometric"      # round 3: CSR prolongators + patch + coarsest inverse
+    n, ref = 8, 1 if geometric else 0
     cfg = _abi.default_config(_abi.AL_STOKES)
     cfg.inner.max_steps = 1000
     plan = partition.slab_partition_stokes3d(n, ref, world)
@@ -29,11 +30,19 @@ def main():
         cfg.inner_prec = _abi.PREC_MULTILEVEL
         cfg.ml_smooth_degree, cfg.ml_smooth_ratio = 2, 8.0
         levels = partition.partitioned_geometric_aggregates(full.params, plan, a=2, min_coarse=100)
+    glevels = None
+    if geometric:
+        cfg.inner_prec = _abi.PREC_MULTILEVEL
+        cfg.inner.max_steps = 100
+        cfg.ml_smooth_degree, cfg.ml_smooth_degree_coarse, cfg.ml_smooth_ratio = 3, 4, 30.0
+        cfg.ml_patch_degree, cfg.ml_patch_ratio, cfg.ml_coarse_direct = 6, 40.0, 1024
+        glevels = problems.tensor_prolongators(full.params, min_coarse=100)
     pb = problems.stokes3d_sphere(n, ref, row_ranges=plan.generator_ranges(rank))
     ctx = solver.Context(0)
     ctx.comm_init_torch()
     ctx.set_partition(plan.offsets)
-    solver.upload_problem(ctx, pb, cfg, partition.local_aggregates(levels, rank) if levels else None)
+    solver.upload_problem(ctx, pb, cfg, partition.local_prolongators(glevels, full.params, plan, rank) if geometric
+                          else partition.local_aggregates(levels, rank) if levels else None)
     rhs = ctx.augment_rhs(cases.rhs_of(pb))
     x, res = ctx.solve(rhs)
     hist = ctx.history()
@@ -43,7 +52,8 @@ def main():
     if rank == 0:
         from oracle import oracle
         osys = oracle.system_from_problem(full, nranks_emulated=world, part_offsets=plan.offsets,
-                                          aggregates=[(a, nc, coff) for a, nc, coff, _ in levels] if levels else None)
+                                          aggregates=glevels if geometric else
+                                          [(a, nc, coff) for a, nc, coff, _ in levels] if levels else None)
         rc, orhs = osys.augment_rhs(cfg, cases.rhs_of(full))
         rc, ox, ores, ohist = osys.solve(cfg, orhs)
         ok = rc == 0

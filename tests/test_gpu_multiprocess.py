@@ -30,7 +30,7 @@ def _launch(nproc, script_args, timeout=900):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
 
 
-@pytest.mark.parametrize("world,mode", [(2, "chebyshev"), (3, "multilevel")])
+@pytest.mark.parametrize("world,mode", [(2, "chebyshev"), (3, "multilevel"), (2, "geometric")])
 def test_partitioned_solve_in_separate_processes_over_gloo(built, world, mode):
     p = _launch(world, [os.path.join(ROOT, "tests", "mp_worker.py"), mode])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]

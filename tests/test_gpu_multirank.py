@@ -338,3 +338,110 @@ def test_partitioned_interface_problems_match_oracle_emulation(built, name, worl
     for b in range(3):
         xs = np.concatenate([out[r]["x"][b] for r in range(world)])
         assert np.allclose(xs, ox[b], rtol=1e-8, atol=1e-9 * max(np.abs(ox[b]).max(), 1e-30))
+
+
+@pytest.mark.parametrize("world,patch", [(2, True), (3, True), (2, False)])
+def test_partitioned_geometric_multigrid_matches_oracle_emulation(built, world, patch):
+    """The round-3 inner preconditioner on a row-partitioned context: CSR prolongators (level 0: each rank's rows, the
+    levels below whole), fine level partitioned, the coarse hierarchy and the interface patch REPLICATED and built
+    partition-independently (remote prolongator / A P rows fetched from their owners, coarse rows formed in global
+    order).  Must equal the oracle's emulation of the partition -- which differs from a single-rank run only in the
+    rank-ordered level-0 reductions -- in every count and to 1e-10 in the history."""
+    n, ref = 8, 1
+    cfg = _abi.default_config(_abi.AL_STOKES)
+    cfg.inner_prec = _abi.PREC_MULTILEVEL
+    cfg.inner.max_steps = 100
+    cfg.ml_smooth_degree, cfg.ml_smooth_degree_coarse, cfg.ml_smooth_ratio = 3, 4, 30.0
+    cfg.ml_coarse_direct = 1024
+    if patch:
+        cfg.ml_patch_degree, cfg.ml_patch_ratio = 6, 40.0
+    full = problems.stokes3d_sphere(n, ref)
+    glevels = problems.tensor_prolongators(full.params, min_coarse=100)
+    plan = partition.slab_partition_stokes3d(n, ref, world)
+    group = solver.LocalGroup(world)
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            pb = problems.stokes3d_sphere(n, ref, row_ranges=plan.generator_ranges(rank))
+            ctx = solver.Context(0)
+            ctx.comm_init_local(group.handle, rank)
+            ctx.set_partition(plan.offsets)
+            solver.upload_problem(ctx, pb, cfg, partition.local_prolongators(glevels, full.params, plan, rank))
+            rhs = ctx.augment_rhs(cases.rhs_of(pb))
+            x, res = ctx.solve(rhs)
+            out[rank] = dict(x=x, res=res.as_dict(), hist=ctx.history())
+            ctx.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    group.close()
+    assert not errs, errs
+    osys = oracle.system_from_problem(full, nranks_emulated=world, part_offsets=plan.offsets, aggregates=glevels)
+    rc, orhs = osys.augment_rhs(cfg, cases.rhs_of(full))
+    rc, ox, ores, ohist = osys.solve(cfg, orhs)
+    assert rc == 0
+    for r in range(world):
+        res = out[r]["res"]
+        assert res["status"] == 0
+        assert (res["outer_iterations"], res["inner_iterations"], res["mp_iterations"]) == \
+            (ores.outer_iterations, ores.inner_iterations, ores.mp_iterations)
+        assert np.array_equal(out[r]["hist"], out[0]["hist"])
+        assert np.max(np.abs(out[r]["hist"] - ohist) / np.abs(ohist)) <= 1e-10
+    for b in range(3):
+        xs = np.concatenate([out[r]["x"][b] for r in range(world)])
+        assert np.allclose(xs, ox[b], rtol=1e-9, atol=1e-10 * max(np.abs(ox[b]).max(), 1e-30))
+
+
+def test_partitioned_geometric_bench_like_solve_matches_single_rank(built):
+    """bench.py's settings on two ranks at a size where the batch-major / window formats carry halo columns (N = 28,
+    mesh bricks per rank): the partition-independent hierarchy gives the SAME iteration counts as the single-rank
+    solve, histories equal up to the differently associated level-0 reductions."""
+    n, ref, world = 28, 1, 2
+    cfg = _abi.bench_multilevel_settings(_abi.default_config(_abi.AL_STOKES), geometric=True)
+    full = problems.stokes3d_sphere(n, ref)
+    glevels = problems.tensor_prolongators(full.params, min_coarse=_abi.BENCH_MIN_COARSE)
+    plan = partition.slab_partition_stokes3d(n, ref, world)
+    group = solver.LocalGroup(world)
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            pb = problems.stokes3d_sphere(n, ref, row_ranges=plan.generator_ranges(rank))
+            ctx = solver.Context(0)
+            ctx.comm_init_local(group.handle, rank)
+            ctx.set_partition(plan.offsets)
+            rb = problems.brick_row_blocks(pb.params, (16, 4, 1),
+                                           node_range=(int(plan.node_offsets_u[rank]), int(plan.node_offsets_u[rank + 1])))
+            solver.upload_problem(ctx, pb, cfg, partition.local_prolongators(glevels, full.params, plan, rank), rb)
+            x, res = ctx.solve(ctx.augment_rhs(cases.rhs_of(pb)))
+            out[rank] = dict(x=x, res=res.as_dict(), hist=ctx.history(), info=ctx.matrix_info(_abi.A))
+            ctx.close()
+        except Exception as e:   # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    group.close()
+    assert not errs, errs
+    ctx = solver.Context(0)
+    ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(full.params, (16, 4, 1)))
+    solver.upload_problem(ctx, full, cfg, glevels)
+    x, res = ctx.solve(ctx.augment_rhs(cases.rhs_of(full)))
+    h1 = ctx.history()
+    ctx.close()
+    for r in range(world):
+        assert out[r]["info"]["batch_major"] == 2
+        assert out[r]["res"]["status"] == 0
+        assert (out[r]["res"]["outer_iterations"], out[r]["res"]["inner_iterations"]) == (res.outer_iterations, res.inner_iterations)
+        assert np.allclose(out[r]["hist"], h1, rtol=1e-6)
+    xs = np.concatenate([out[r]["x"][0] for r in range(world)])
+    assert np.allclose(xs, x[0], rtol=1e-6, atol=1e-8 * np.abs(x[0]).max())
