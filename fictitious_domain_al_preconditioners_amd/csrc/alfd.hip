@@ -103,7 +103,7 @@ struct DevCsr {
     bool on = false, bricks = false;
     int64_t nb = 0, nseg = 0, stream_bytes = 0, nbatch = 0, dict_total = 0, shared_nnz = 0;
     int32_t stride = 0, maxW = 0;
-    int32_t L = 64, tab_u64 = 8;   // lanes per row of the format; descriptor words per batch
+    int32_t L = 64, tab_u64 = 16;  // lanes per row of the format; descriptor words per batch
     int32_t wide = 0;              // 10-bit codes / 11-bit window columns (VsFmt<1>)
     uint8_t *stream = nullptr;
     int64_t *sb = nullptr;
@@ -1998,10 +1998,11 @@ struct VsPlan {
   int64_t nb_in = 0;  // blocks before the dictionary limit halved any
 };
 
+constexpr int kVsBatchRows = 16;   // rows a batch descriptor names (16 x uint64 = 128 bytes)
 struct VsBatch {
-  int cls, nreal, id[8];   // plain: up to 4 rows; shared: up to 8
-  bool shared;             // the rows are translates of one another: one template + a window shift per row
-  int32_t shift[8];        // window slots, relative to row id[0]
+  int cls, nreal, id[kVsBatchRows];   // plain: up to 4 rows; shared: up to 16
+  bool shared;                        // the rows are translates of one another: one template + a window shift per row
+  int32_t shift[kVsBatchRows];        // window slots, relative to row id[0]
 };
 
 // x window of a row block: maximal runs of used columns, gaps shorter than GAP bridged, cut into pieces
@@ -2104,10 +2105,10 @@ static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, cons
         size_t g1 = g0 + 1;
         while (share && g1 < ids.size() && key[ids[g1]] == key[ids[g0]] && same(ids[g0], ids[g1])) ++g1;
         size_t q = g0;
-        while (g1 - q >= 2) {   // 2..8 rows per shared batch (never a lone leftover if it can be avoided)
+        while (g1 - q >= 2) {   // 2..16 rows per shared batch (never a lone leftover if it can be avoided)
           const size_t left = g1 - q;
-          const size_t take = left == 9 ? 5 : std::min<size_t>(8, left);
-          VsBatch bt{cls, 0, {0, 0, 0, 0, 0, 0, 0, 0}, true, {0, 0, 0, 0, 0, 0, 0, 0}};
+          const size_t take = left == kVsBatchRows + 1 ? kVsBatchRows / 2 + 1 : std::min<size_t>(kVsBatchRows, left);
+          VsBatch bt{cls, 0, {}, true, {}};
           for (size_t i = q; i < q + take; ++i) {
             bt.id[bt.nreal] = ids[i];
             bt.shift[bt.nreal] = first[ids[i]] - first[ids[q]];
@@ -2123,7 +2124,7 @@ static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, cons
     // plain batches: longest first, so that the rows of a batch have equal or close remainders in the last chunk
     std::stable_sort(plain.begin(), plain.end(), [&](int a, int b) { return len[a] != len[b] ? len[a] > len[b] : a < b; });
     for (size_t q = 0; q < plain.size(); q += 4) {
-      VsBatch bt{cls, 0, {0, 0, 0, 0, 0, 0, 0, 0}, false, {0, 0, 0, 0, 0, 0, 0, 0}};
+      VsBatch bt{cls, 0, {}, false, {}};
       for (size_t i = q; i < std::min(q + 4, plain.size()); ++i) bt.id[bt.nreal++] = plain[i];
       out.push_back(bt);
     }
@@ -2278,7 +2279,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
   pl.stride = maxb;
   pl.rbs = maxr;
   pl.stream.assign((size_t)tot + 4096, 0);
-  pl.tab.assign((size_t)nb * maxb * 8, 0);
+  pl.tab.assign((size_t)nb * maxb * kVsBatchRows, 0);
   pl.cnt.assign(nb, 0);
   pl.blkW.assign(nb, 0);
   pl.dn.assign(nb, 0);
@@ -2327,8 +2328,8 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
           for (size_t q = 0; q < bts.size() && !bad; ++q) {
             const VsBatch &bt = bts[q];
             uint8_t *fb = sp + 16 * (size_t)eoff;
-            uint64_t *dst = &pl.tab[((size_t)b * maxb + q) * 8];
-            for (int i = 0; i < 8 && !bad; ++i) {
+            uint64_t *dst = &pl.tab[((size_t)b * maxb + q) * kVsBatchRows];
+            for (int i = 0; i < kVsBatchRows && !bad; ++i) {
               const int src = i < bt.nreal ? i : 0;     // fillers repeat the batch's first row
               const int32_t r = rows[bt.id[src]];
               const int64_t k0 = rp[r], n = rp[r + 1] - k0;
@@ -2346,10 +2347,10 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
                     cell[2] = (uint8_t)(f >> 16);
                   }
                 }
-              // low 20 bits: the batch's offset; rows 1.. of a shared batch: their window shift in bytes + 2^19
-              const uint64_t low = (bt.shared && i > 0) ? (uint64_t)((i < bt.nreal ? bt.shift[i] * 8 : 0) + (1 << 19)) : eoff;
-              dst[i] = low | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) |
-                       ((uint64_t)(i < bt.nreal ? (uint32_t)r : 0xffffffffu) << 32);
+              // low dword: offset | count | class; rows 1.. of a shared batch: their window shift in bytes (signed)
+              const uint64_t low = (bt.shared && i > 0) ? (uint64_t)(uint32_t)(i < bt.nreal ? bt.shift[i] * 8 : 0)
+                                                        : ((uint64_t)eoff | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29));
+              dst[i] = low | ((uint64_t)(i < bt.nreal ? (uint32_t)r : 0xffffffffu) << 32);
             }
             if (bt.shared) dst[0] |= 1ull << 63;
             eoff += (uint32_t)vs_batch_units(bt, rows, rp);
@@ -2624,7 +2625,7 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
               ctx->rb_ptr[slot].data(), ctx->rb_rows[slot].data(), pw, ctx->vs_share != 0, 1);
     else
       plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pw, ctx->vs_share != 0, 1);
-    if (pw.ok && (!pl.ok || pw.stream.size() + 64 * (size_t)pw.nbatch < pl.stream.size() + 64 * (size_t)pl.nbatch)) pl = std::move(pw);
+    if (pw.ok && (!pl.ok || pw.stream.size() + 128 * (size_t)pw.nbatch < pl.stream.size() + 128 * (size_t)pl.nbatch)) pl = std::move(pw);
   }
   if (!pl.ok) return ALFD_OK;
   DevCsr::Vs &v = m.vs;
@@ -5843,7 +5844,7 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
     VsPlan pw;
     if (n_blocks > 0) plan_vs(nrows, rp, col, val, row_block, 4096, 8, n_blocks, block_ptr, rows, pw, true, 1);
     else plan_vs(nrows, rp, col, val, row_block, 4096, 8, 0, nullptr, nullptr, pw, true, 1);
-    if (pw.ok && (!pl.ok || pw.stream.size() + 64 * (size_t)pw.nbatch < pl.stream.size() + 64 * (size_t)pl.nbatch)) pl = std::move(pw);
+    if (pw.ok && (!pl.ok || pw.stream.size() + 128 * (size_t)pw.nbatch < pl.stream.size() + 128 * (size_t)pl.nbatch)) pl = std::move(pw);
   }
   const int code_shift = pl.wide ? VsFmt<1>::kCodeShift : VsFmt<0>::kCodeShift;
   out->ok = pl.ok ? 1 : 0;
@@ -5871,14 +5872,14 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
     const uint8_t *sp = pl.stream.data() + pl.sb[b];
     if (pl.sb[b] % 16) ++bad;
     for (int q = 0; q < nbt; ++q) {
-      const uint64_t *dsc = &pl.tab[((size_t)b * pl.stride + q) * 8];
+      const uint64_t *dsc = &pl.tab[((size_t)b * pl.stride + q) * kVsBatchRows];
       auto off = [](uint64_t dd) { return (uint32_t)dd & 0xfffffu; };
       auto cnt_of = [](uint64_t dd) { return ((uint32_t)dd >> 20) & 0x1ffu; };
       const uint32_t eb = off(dsc[0]);
       const bool shared = (dsc[0] >> 63) != 0;
       const int cls = (int)(((uint32_t)dsc[0] >> 29) & 7u);
       const uint8_t *fb = sp + 16 * (size_t)eb;
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < kVsBatchRows; ++i) {
         const uint32_t rfield = (uint32_t)(dsc[i] >> 32) & (i == 0 ? 0x7fffffffu : 0xffffffffu);
         if (!shared && i >= 4 && (int32_t)rfield >= 0) ++bad;   // plain batches hold 4 rows
         const int64_t r = (int32_t)rfield;
@@ -5886,10 +5887,10 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
         if (r >= nrows || seen[r]) { ++bad; continue; }
         seen[r] = 1;
         ++covered;
-        const uint32_t n = cnt_of(dsc[i]);
+        const uint32_t n = cnt_of(dsc[shared ? 0 : i]);        // translates share the template's count
         if ((int64_t)n != rp[r + 1] - rp[r] || (int)((n + 63) / 64) != cls) { ++bad; continue; }
-        if (shared ? n != cnt_of(dsc[0]) : off(dsc[i]) != eb) { ++bad; continue; }
-        const int32_t shift = (shared && i > 0) ? (int32_t)off(dsc[i]) - (1 << 19) : 0;   // bytes
+        if (!shared && off(dsc[i]) != eb) { ++bad; continue; }
+        const int32_t shift = (shared && i > 0) ? (int32_t)(uint32_t)dsc[i] : 0;   // bytes
         if (shift % 8) ++bad;
         for (uint32_t k = 0; k < n; ++k) {
           uint32_t f;

@@ -34,19 +34,19 @@ constexpr int kMaxBasis = 64;        // max FGMRES basis vectors handled by the 
 __device__ __forceinline__ double dpp_xor_mov(double v, int which) {
   int lo = __double2loint(v), hi = __double2hiint(v), rl, rh;
   if (which == 8) {
-    rl = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false);  // row_ror:8
-    rh = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false);
+    rl = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, true);  // row_ror:8 (bound_ctrl: no "old" operand to set up)
+    rh = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, true);
   } else if (which == 4) {
     rl = __builtin_amdgcn_update_dpp(0, lo, 0x104, 0xf, 0x5, false);   // row_shl:4 -> banks 0,2
     rl = __builtin_amdgcn_update_dpp(rl, lo, 0x114, 0xf, 0xa, false);  // row_shr:4 -> banks 1,3
     rh = __builtin_amdgcn_update_dpp(0, hi, 0x104, 0xf, 0x5, false);
     rh = __builtin_amdgcn_update_dpp(rh, hi, 0x114, 0xf, 0xa, false);
   } else if (which == 2) {
-    rl = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
-    rh = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false);
+    rl = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    rh = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, true);
   } else {
-    rl = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
-    rh = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+    rl = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    rh = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true);
   }
   return __hiloint2double(rh, rl);
 }
@@ -92,8 +92,8 @@ __device__ __forceinline__ double group_reduce(double v) {
 template <int N>
 __device__ __forceinline__ double dpp_shl(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int rl = __builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xf, 0xf, false);
-  const int rh = __builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xf, 0xf, false);
+  const int rl = __builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xf, 0xf, true);   // bound_ctrl: the lanes shifted in read 0
+  const int rh = __builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xf, 0xf, true);
   return __hiloint2double(rh, rl);
 }
 // Last four tree steps inside 16-lane rows, valid in lane 0 of every row (the lane that stores): after the
@@ -141,6 +141,43 @@ __device__ __forceinline__ double reduce_rows8(double a0, double a1, double a2, 
   x = x + dpp_shl<2>(x);
   x = x + dpp_shl<1>(x);
   return x;
+}
+
+// lane l <- lane l - N of its 16-lane row (row_shr:N; the bottom N lanes of a row read 0)
+template <int N>
+__device__ __forceinline__ double dpp_shr(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int rl = __builtin_amdgcn_update_dpp(0, lo, 0x110 + N, 0xf, 0xf, true);
+  const int rh = __builtin_amdgcn_update_dpp(0, hi, 0x110 + N, 0xf, 0xf, true);
+  return __hiloint2double(rh, rl);
+}
+// Trees of 16 rows in 66 vector instructions: the l^32 and l^16 steps leave four registers of 4 rows x 16 lanes, the l^8
+// step folds each to 8 lanes per row and pairs of them merge (lanes 0..7 / 8..15 of a 16-lane row), the l^4 step folds
+// to 4 lanes per row -- the first register towards the lanes with bit 2 clear (partner l + 4), the second towards those
+// with bit 2 set (partner l - 4; a + b is b + a bit for bit) -- and the two merge into ONE register; the last two steps
+// feed the lane that stores.  Result of row {0, 2, 1, 3}[lane >> 4] + 4 * ((lane >> 3) & 1) + 8 * ((lane >> 2) & 1) in
+// the lanes with lane % 4 == 0.  Same pairs in the same order as group_reduce<64> for every row.
+__device__ __forceinline__ double reduce_rows16(double (&a)[16], int lane) {
+  double p[8], u[4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    swap32(a[2 * j], a[2 * j + 1]);
+    p[j] = a[2 * j] + a[2 * j + 1];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    swap16(p[2 * j], p[2 * j + 1]);
+    u[j] = p[2 * j] + p[2 * j + 1];   // 16-lane rows: rows 4 j + {0, 2, 1, 3}
+    u[j] = u[j] + dpp_xor_mov(u[j], 8);
+  }
+  const bool h = (lane & 8) != 0;
+  double x0 = h ? u[1] : u[0], x1 = h ? u[3] : u[2];
+  x0 = x0 + dpp_shl<4>(x0);
+  x1 = x1 + dpp_shr<4>(x1);
+  double z = (lane & 4) ? x1 : x0;
+  z = z + dpp_shl<2>(z);
+  z = z + dpp_shl<1>(z);
+  return z;
 }
 
 // Trees of 2 rows: row 0 in lanes 0..31, row 1 in lanes 32..63.

@@ -50,13 +50,13 @@ struct VsFmt {
 };
 constexpr int kVsMaxLen = 384;    // longest row the format takes (class 6)
 
-// batch descriptor: 8 x uint64, one per row: eb (20 bits) | entry count (9) | class = ceil(count / 64) (3)
-// | global row, 0xffffffff = filler (32).  eb: the batch's offset from the block's first byte in 16-byte
+// batch descriptor: 16 x uint64 (128 bytes), one per row: eb (20 bits) | entry count (9) | class = ceil(count / 64)
+// (3) | global row, 0xffffffff = filler (32).  eb: the batch's offset from the block's first byte in 16-byte
 // units.  Plain batches use rows 0..3 (fillers repeat row 0).  Bit 63 of row 0 marks a SHARED batch
-// (vs_shared) of up to 8 rows; there the low 20 bits of rows 1.. hold the row's window shift in bytes + 2^19.
-__device__ __forceinline__ uint32_t vs_off(uint64_t d) { return (uint32_t)d & 0xfffffu; }
-__device__ __forceinline__ int32_t vs_len(uint64_t d) { return (int32_t)(((uint32_t)d >> 20) & 0x1ffu); }
-__device__ __forceinline__ int vs_cls(uint64_t d) { return (int)(((uint32_t)d >> 29) & 7u); }
+// (vs_shared) of up to 16 rows; there the low dword of rows 1.. is the row's window shift in bytes (signed).
+__device__ __forceinline__ uint32_t vs_off(uint32_t d) { return d & 0xfffffu; }
+__device__ __forceinline__ int32_t vs_len(uint32_t d) { return (int32_t)((d >> 20) & 0x1ffu); }
+__device__ __forceinline__ int vs_cls(uint32_t d) { return (int)((d >> 29) & 7u); }
 
 // LDS read at a byte offset from the start of the workgroup's LDS (the kernel has no static
 // __shared__ data, so its dynamic array starts at 0): no symbol, so nothing is added to the offset
@@ -84,7 +84,6 @@ struct VsWord3 {
 // (f >> 12) & 0xff8.  ONE global_load_dwordx3 per chunk serves all four rows.  The last chunk is
 // partial: only lanes below the batch's longest remainder are stored (rows of a class are sorted by
 // length, so the remainders of a batch are equal or close); rem[i] masks row i's fma.
-// All loads of the batch are issued before the first use.
 template <int NCH, int WD>
 __device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem, int lane,
                                          const uint8_t *__restrict__ fb, const char *sm, double (&acc)[4]) {
@@ -120,32 +119,51 @@ __device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem
 // entry, window columns differing by one constant per row) -- the rows of one node type inside a mesh
 // brick.  One row is stored (a dword per lane and chunk, lane-major), the others add their window shift
 // sh[i] (bytes): 1/R of the stream, one dictionary gather instead of R.
-template <int NCH, int R, int WD>
-__device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[R], int lane,
-                                          const uint8_t *__restrict__ fb, double (&acc)[R]) {
-  uint32_t w[NCH];
+// Its stream words are fetched ONE BATCH AHEAD (vs_shared_fetch, issued before the tree and the store of the batch
+// in front, or before the block frame for a wave's first batch): a wave spent most of a batch's ~7 000 cycles waiting
+// for exactly this round trip.  w[0] = the last, partial chunk; w[1 + j] = full chunk j (static register indices for
+// every chunk count).
+__device__ __forceinline__ void vs_shared_fetch(uint32_t d0, const uint8_t *__restrict__ sbase, int lane, uint32_t (&w)[6]) {
+  const int cls = vs_cls(d0);
+  const uint8_t *fb = sbase + 16u * (size_t)vs_off(d0);
+  const int32_t rem = vs_len(d0) - 64 * (cls - 1);
+  w[0] = *(const uint32_t *)(fb + 256 * (cls - 1) + 4 * (lane < rem ? lane : rem - 1));
 #pragma unroll
-  for (int j = 0; j < NCH - 1; ++j) w[j] = *(const uint32_t *)(fb + 256 * j + 4 * lane);
-  w[NCH - 1] = *(const uint32_t *)(fb + 256 * (NCH - 1) + 4 * (lane < rem ? lane : rem - 1));
+  for (int j = 0; j < 5; ++j)
+    if (j < cls - 1) w[1 + j] = *(const uint32_t *)(fb + 256 * j + 4 * lane);
+}
+
+template <int NCH, int R, int WD>
+__device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[R], int lane, const uint32_t (&w)[6],
+                                          double (&acc)[R]) {
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
-    const uint32_t lc = w[j] & VsFmt<WD>::kColMask;
-    double v = vs_lds_f64(kVsDictOff + ((w[j] >> VsFmt<WD>::kDictShift) & VsFmt<WD>::kDictMask));
-    double xv[R];
+    const uint32_t wj = j == NCH - 1 ? w[0] : w[1 + (j < 5 ? j : 0)];
+    const uint32_t lc = wj & VsFmt<WD>::kColMask;
+    double v = vs_lds_f64(kVsDictOff + ((wj >> VsFmt<WD>::kDictShift) & VsFmt<WD>::kDictMask));
+    constexpr int G = R > 8 ? 4 : R;   // gathers in flight (a 16-row batch takes four rounds: with 8 the kernel spills, 0.64 instead of 0.44 ms)
 #pragma unroll
-    for (int i = 0; i < R; ++i) xv[i] = vs_lds_f64(VsFmt<WD>::kWinOff + (uint32_t)((int32_t)lc + sh[i]));
+    for (int g = 0; g < R; g += G) {
+      double xv[G];
 #pragma unroll
-    for (int i = 0; i < R; ++i) asm volatile("" : "+v"(xv[i]));
-    asm volatile("" : "+v"(v));
-    if (j == NCH - 1) {
-      if (lane < rem) {   // one exec mask around the fmas (the empty asm keeps it a branch, not 2 R selects)
-        asm volatile("");
+      for (int i = 0; i < G; ++i) xv[i] = vs_lds_f64(VsFmt<WD>::kWinOff + (uint32_t)((int32_t)lc + sh[g + i]));
 #pragma unroll
-        for (int i = 0; i < R; ++i) acc[i] = fma(v, xv[i], acc[i]);
+      for (int i = 0; i < G; ++i) asm volatile("" : "+v"(xv[i]));
+      if (g == 0) asm volatile("" : "+v"(v));
+      if (j == NCH - 1) {
+        if (lane < rem) {   // one exec mask around the fmas (the empty asm keeps it a branch, not 2 G selects)
+          asm volatile("");
+#pragma unroll
+          for (int i = 0; i < G; ++i) acc[g + i] = fma(v, xv[i], acc[g + i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < G; ++i) acc[g + i] = fma(v, xv[i], acc[g + i]);
       }
-    } else {
+      if (R > 8) {   // round by round: G gathers, G fmas (left alone the fmas sink below ALL gathers of the batch: spills)
 #pragma unroll
-      for (int i = 0; i < R; ++i) acc[i] = fma(v, xv[i], acc[i]);
+        for (int i = 0; i < G; ++i) asm volatile("" : "+v"(acc[g + i]));
+      }
     }
   }
 }
@@ -172,12 +190,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   }
   const int32_t nbatch = cnt[b];
   const uint8_t *sbase = stream + sb[b];
-  const uint64_t *bt = tab + ((int64_t)b * stride + wave) * 8;
-  uint64_t nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (wave < nbatch) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) nx[i] = bt[i];
-  }
+  // Batch descriptors travel through the VECTOR memory path, two batches ahead: lane k of either half-wave holds dword k
+  // of a descriptor, the scalars come out of it with v_readlane.  (An s_load one batch ahead, as before, sat in the same
+  // lgkmcnt counter as the LDS gathers, and scalar loads return out of order: the first gather wait of every batch also
+  // waited for the descriptor of the NEXT one -- a full HBM round trip per batch, the kernel ran at the speed of that.)
+  const uint32_t *tb = (const uint32_t *)(tab + (int64_t)b * stride * 16);
+  const int hl = lane & 31;
+  auto hdr_load = [&](int32_t q) {   // the block's batch q, clamped to the last one (no branch around a load)
+    const int32_t qq = q < nbatch ? q : (nbatch > 0 ? nbatch - 1 : 0);
+    return tb[32 * (int64_t)qq + hl];
+  };
+  auto hdr = [](uint32_t hv, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)hv, k); };
+  uint32_t hv1 = hdr_load(wave);
+  uint32_t w[6];
+  if (wave < nbatch && (int32_t)hdr(hv1, 1) < 0) vs_shared_fetch(hdr(hv1, 0), sbase, lane, w);   // in flight during the block frame
+  uint32_t hv2 = hdr_load(wave + NW);
   {  // block frame: dictionary and x window (segments of at most 64 slots, 4 in flight per wave)
     const int32_t nd = blk_dict_n[b];
     for (int t = threadIdx.x; t < nd; t += 64 * NW) ds[t] = dict[blk_dict_off[b] + t];
@@ -205,11 +232,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
   }
   __syncthreads();
-  auto store4 = [&](double s, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3) {
-    const int q = lane >> 4;  // 16-lane row q holds the tree of batch row {0, 2, 1, 3}[q]
-    const uint64_t dq = q == 0 ? d0 : (q == 1 ? d2 : (q == 2 ? d1 : d3));
-    const int32_t r = (int32_t)(dq >> 32);
-    if ((lane & 15) == 0 && r >= 0) {
+  // The lane that ends up with a row's tree value stores it.  Which row that is depends on the lane alone --
+  // batch row {0, 2, 1, 3}[lane / 16] + 4 * (bit 3 of the lane) + 8 * (bit 2), see reduce_rows16 / 8 / 4 -- so every
+  // lane reads the global row number of "its" row out of the descriptor register with one ds_bpermute (the rows a
+  // smaller batch does not have are fillers, -1) instead of selecting it out of the descriptor's scalars.
+  const int q16 = lane >> 4;
+  const int rsel = 4 * (2 * ((((q16 & 1) << 1) | (q16 >> 1)) + 4 * ((lane >> 3) & 1) + 8 * ((lane >> 2) & 1)) + 1);   // ds_bpermute address of that dword
+  const uint32_t rmask = lane < 8 ? 0x7fffffffu : 0xffffffffu;     // bit 63 of row 0 is the shared-batch flag
+  auto store = [&](double s, int32_t r, bool mine) {
+    if (mine && r >= 0) {
       if (EPI == 0)
         y[r] = s;
       else if (EPI == 1)
@@ -223,88 +254,88 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
   };
   for (int32_t bi = wave; bi < nbatch; bi += NW) {
-    uint64_t desc[8];
+    uint32_t lo[16];   // low dwords of the rows: offset | count | class (row 0, plain rows), window shifts (shared rows 1..)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) desc[i] = nx[i];
-    bt += 8 * NW;
-    if (bi + NW < nbatch) {  // next descriptor: one s_load_dwordx16, in flight during this batch
-#pragma unroll
-      for (int i = 0; i < 8; ++i) nx[i] = bt[i];
-    }
-    const uint32_t eb = vs_off(desc[0]);
-    const int cls = vs_cls(desc[0]);
+    for (int i = 0; i < 16; ++i) lo[i] = hdr(hv1, 2 * i);
+    const bool shared = (int32_t)hdr(hv1, 1) < 0;                       // wave-uniform
+    const bool sixteen = shared && (int32_t)hdr(hv1, 17) >= 0;          // a ninth row
+    const bool eight = shared && !sixteen && (int32_t)hdr(hv1, 9) >= 0;  // a fifth row
+    const int32_t rid = (int32_t)((uint32_t)__builtin_amdgcn_ds_bpermute(rsel, (int)hv1) & rmask);
+    const uint32_t eb = vs_off(lo[0]);
+    const int cls = vs_cls(lo[0]);
     const int32_t full = cls > 0 ? 64 * (cls - 1) : 0;
     const uint8_t *fb = sbase + 16u * (size_t)eb;
-    const bool shared = (int64_t)desc[0] < 0;           // wave-uniform
-    desc[0] &= 0x7fffffffffffffffull;                    // bit 63 was the flag, not part of the row
-    if (shared && (int32_t)(desc[4] >> 32) >= 0) {       // 5..8 translates
-      const int32_t rem = vs_len(desc[0]) - full;
+    if (sixteen) {                                       // 9..16 translates
+      const int32_t rem = vs_len(lo[0]) - full;
+      int32_t sh[16];
+      sh[0] = 0;
+#pragma unroll
+      for (int i = 1; i < 16; ++i) sh[i] = (int32_t)lo[i];
+      double acc[16] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      switch (cls) {
+        case 1: vs_shared<1, 16, WD>(rem, sh, lane, w, acc); break;
+        case 2: vs_shared<2, 16, WD>(rem, sh, lane, w, acc); break;
+        case 3: vs_shared<3, 16, WD>(rem, sh, lane, w, acc); break;
+        case 4: vs_shared<4, 16, WD>(rem, sh, lane, w, acc); break;
+        case 5: vs_shared<5, 16, WD>(rem, sh, lane, w, acc); break;
+        default: vs_shared<6, 16, WD>(rem, sh, lane, w, acc); break;
+      }
+      // lane 16 q + 8 h + 4 g holds the tree of batch row {0, 2, 1, 3}[q] + 4 h + 8 g
+      store(reduce_rows16(acc, lane), rid, (lane & 3) == 0);
+    } else if (eight) {                                  // 5..8 translates
+      const int32_t rem = vs_len(lo[0]) - full;
       int32_t sh[8];
       sh[0] = 0;
 #pragma unroll
-      for (int i = 1; i < 8; ++i) sh[i] = (int32_t)vs_off(desc[i]) - (1 << 19);
+      for (int i = 1; i < 8; ++i) sh[i] = (int32_t)lo[i];
       double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       switch (cls) {
-        case 1: vs_shared<1, 8, WD>(rem, sh, lane, fb, acc); break;
-        case 2: vs_shared<2, 8, WD>(rem, sh, lane, fb, acc); break;
-        case 3: vs_shared<3, 8, WD>(rem, sh, lane, fb, acc); break;
-        case 4: vs_shared<4, 8, WD>(rem, sh, lane, fb, acc); break;
-        case 5: vs_shared<5, 8, WD>(rem, sh, lane, fb, acc); break;
-        default: vs_shared<6, 8, WD>(rem, sh, lane, fb, acc); break;
+        case 1: vs_shared<1, 8, WD>(rem, sh, lane, w, acc); break;
+        case 2: vs_shared<2, 8, WD>(rem, sh, lane, w, acc); break;
+        case 3: vs_shared<3, 8, WD>(rem, sh, lane, w, acc); break;
+        case 4: vs_shared<4, 8, WD>(rem, sh, lane, w, acc); break;
+        case 5: vs_shared<5, 8, WD>(rem, sh, lane, w, acc); break;
+        default: vs_shared<6, 8, WD>(rem, sh, lane, w, acc); break;
       }
-      const double s8 = reduce_rows8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], lane);
       // lane 16 q + 8 h (q = 0..3, h = 0..1) holds the tree of batch row {0, 2, 1, 3}[q] + 4 h
-      const bool h = (lane & 8) != 0, q1 = (lane & 16) != 0, q2 = (lane & 32) != 0;
-      const int32_t r0 = h ? (int32_t)(desc[4] >> 32) : (int32_t)(desc[0] >> 32);
-      const int32_t r1 = h ? (int32_t)(desc[5] >> 32) : (int32_t)(desc[1] >> 32);
-      const int32_t r2 = h ? (int32_t)(desc[6] >> 32) : (int32_t)(desc[2] >> 32);
-      const int32_t r3 = h ? (int32_t)(desc[7] >> 32) : (int32_t)(desc[3] >> 32);
-      const int32_t r = q2 ? (q1 ? r3 : r1) : (q1 ? r2 : r0);
-      if ((lane & 7) == 0 && r >= 0) {
-        if (EPI == 0)
-          y[r] = s8;
-        else if (EPI == 1)
-          y[r] = fma(alpha, s8, y[r]);
-        else if (EPI == 2)
-          y[r] = d[r] * s8;
-        else {
-          y[r] = s8;
-          y2[r] = d[r] * s8;
+      store(reduce_rows8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], lane), rid, (lane & 7) == 0);
+    } else {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (shared) {   // 2..4 translates
+        const int32_t rem = vs_len(lo[0]) - full;
+        const int32_t sh[4] = {0, (int32_t)lo[1], (int32_t)lo[2], (int32_t)lo[3]};
+        switch (cls) {
+          case 1: vs_shared<1, 4, WD>(rem, sh, lane, w, acc); break;
+          case 2: vs_shared<2, 4, WD>(rem, sh, lane, w, acc); break;
+          case 3: vs_shared<3, 4, WD>(rem, sh, lane, w, acc); break;
+          case 4: vs_shared<4, 4, WD>(rem, sh, lane, w, acc); break;
+          case 5: vs_shared<5, 4, WD>(rem, sh, lane, w, acc); break;
+          default: vs_shared<6, 4, WD>(rem, sh, lane, w, acc); break;
+        }
+      } else {
+        int32_t rem[4], maxrem = 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rem[i] = vs_len(lo[i]) - full;
+          maxrem = rem[i] > maxrem ? rem[i] : maxrem;
+        }
+        switch (cls) {
+          case 1: vs_batch<1, WD>(rem, maxrem, lane, fb, sm, acc); break;
+          case 2: vs_batch<2, WD>(rem, maxrem, lane, fb, sm, acc); break;
+          case 3: vs_batch<3, WD>(rem, maxrem, lane, fb, sm, acc); break;
+          case 4: vs_batch<4, WD>(rem, maxrem, lane, fb, sm, acc); break;
+          case 5: vs_batch<5, WD>(rem, maxrem, lane, fb, sm, acc); break;
+          case 6: vs_batch<6, WD>(rem, maxrem, lane, fb, sm, acc); break;
+          default: break;  // class 0: empty rows
         }
       }
-      continue;
+      store(reduce_rows4(acc[0], acc[1], acc[2], acc[3]), rid, (lane & 15) == 0);   // 16-lane row q: batch row {0, 2, 1, 3}[q]
     }
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (shared) {   // 2..4 translates
-      const int32_t rem = vs_len(desc[0]) - full;
-      const int32_t sh[4] = {0, (int32_t)vs_off(desc[1]) - (1 << 19), (int32_t)vs_off(desc[2]) - (1 << 19),
-                             (int32_t)vs_off(desc[3]) - (1 << 19)};
-      switch (cls) {
-        case 1: vs_shared<1, 4, WD>(rem, sh, lane, fb, acc); break;
-        case 2: vs_shared<2, 4, WD>(rem, sh, lane, fb, acc); break;
-        case 3: vs_shared<3, 4, WD>(rem, sh, lane, fb, acc); break;
-        case 4: vs_shared<4, 4, WD>(rem, sh, lane, fb, acc); break;
-        case 5: vs_shared<5, 4, WD>(rem, sh, lane, fb, acc); break;
-        default: vs_shared<6, 4, WD>(rem, sh, lane, fb, acc); break;
-      }
-    } else {
-      int32_t rem[4], maxrem = 1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rem[i] = vs_len(desc[i]) - full;
-        maxrem = rem[i] > maxrem ? rem[i] : maxrem;
-      }
-      switch (cls) {
-        case 1: vs_batch<1, WD>(rem, maxrem, lane, fb, sm, acc); break;
-        case 2: vs_batch<2, WD>(rem, maxrem, lane, fb, sm, acc); break;
-        case 3: vs_batch<3, WD>(rem, maxrem, lane, fb, sm, acc); break;
-        case 4: vs_batch<4, WD>(rem, maxrem, lane, fb, sm, acc); break;
-        case 5: vs_batch<5, WD>(rem, maxrem, lane, fb, sm, acc); break;
-        case 6: vs_batch<6, WD>(rem, maxrem, lane, fb, sm, acc); break;
-        default: break;  // class 0: empty rows
-      }
-    }
-    store4(reduce_rows4(acc[0], acc[1], acc[2], acc[3]), desc[0], desc[1], desc[2], desc[3]);
+    // the stream words of the wave's next shared batch (the ONE place of the loop that writes w: no copies of loaded
+    // values, which would have to wait for them), and behind them the descriptor of the batch after that
+    hv1 = hv2;
+    if (bi + NW < nbatch && (int32_t)hdr(hv1, 1) < 0) vs_shared_fetch(hdr(hv1, 0), sbase, lane, w);
+    hv2 = hdr_load(bi + 2 * NW);
   }
 }
 
