@@ -1,0 +1,18 @@
+"""Times the A-SpMV (N = 74, mesh bricks 16x4x1) with an alternative build of the library: ablation experiments."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fictitious_domain_al_preconditioners_amd import problems, solver, _abi
+if len(sys.argv) > 1 and sys.argv[1] != "base":
+    solver.LIB_PATH = os.path.abspath(sys.argv[1])
+N = int(os.environ.get("ABL_N", "74"))
+pb = problems.stokes3d_sphere(n_cells=N, immersed_refine=4)
+m = pb.mats["A"]
+ctx = solver.Context(0)
+ctx.set_row_blocks(_abi.A, *problems.brick_row_blocks(pb.params, (16, 4, 1)))
+ctx.set_matrix(_abi.A, m)
+info = ctx.matrix_info(_abi.A)
+best = 1e9
+for _ in range(3):
+    ms, nbytes = ctx.bench_spmv_format(_abi.A, 30, True)
+    best = min(best, ms)
+print(f"{sys.argv[1] if len(sys.argv) > 1 else 'base':40s} {best:.4f} ms  fmt {info['batch_major']}", flush=True)
