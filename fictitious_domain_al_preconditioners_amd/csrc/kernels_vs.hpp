@@ -16,16 +16,17 @@
 //        global_load_dwordx3 instead of eight 1- and 2-byte loads (a wave-level load costs ~8.5 issue
 //        cycles whether it carries 1 or 4 bytes per lane; with brick windows the stream loads were what
 //        bounded the kernel: ablation without them 0.61 ms, without the LDS gathers 1.29 of 1.30 ms);
-//      - shared batch (2..8 rows that are translates of one another: same length, same values entry by
+//      - shared batch (2..16 rows that are translates of one another: same length, same values entry by
 //        entry, window columns differing by one constant per row -- the rows of one node type inside a
 //        brick of a uniform mesh): ONE stored row, a dword at 256 j + 4 l, plus a window shift per row;
 //        one dictionary gather serves all rows.  96 % of the entries of the Stokes velocity block;
 //    of the last, partial chunk only the lanes below the batch's longest remainder are stored;
-//  * the 64-byte batch descriptor names the GLOBAL row of each row, so the sums go straight to y.
+//  * the 128-byte batch descriptor names the GLOBAL row of each row, so the sums go straight to y.
 //
-// At N = 74: 0.83 B/nnz, 0.53..0.58 ms per launch (round-1 kernel: 6.08 GB, 1.5 ms); bound by the vector
-// ALU (~72 % of the issue slots: window-offset adds, fma, the 4-row trees) and the LDS gather rate, not by
-// HBM.  History of the variants, incl. an LDS-DMA one that lost: DESIGN.md section 5, profiles/r02/.
+// At N = 74: 0.445 ms per launch (round 2: 0.52 ms with 8-row batches; round-1 kernel: 6.08 GB, 1.5 ms).  The time is
+// t = 2.6 ms / (waves per SIMD) + 0.19 ms (measured by padding the LDS request): what counts is the serial length of
+// one wave's instruction stream per row -- hence 16 rows per batch, descriptors that never touch the scalar memory
+// path, row numbers by ds_bpermute.  Experiments and history: DESIGN.md section 5, profiles/r03/, profiles/r02/.
 #pragma once
 
 namespace alfd {
@@ -89,8 +90,8 @@ __device__ __forceinline__ void vs_batch(const int32_t (&rem)[4], int32_t maxrem
                                          const uint8_t *__restrict__ fb, const char *sm, double (&acc)[4]) {
   VsWord3 w[NCH];
 #pragma unroll
-  for (int j = 0; j < NCH - 1; ++j) w[j] = *(const VsWord3 *)(fb + 768 * j + 12 * lane);
-  w[NCH - 1] = *(const VsWord3 *)(fb + 768 * (NCH - 1) + 12 * (lane < maxrem ? lane : maxrem - 1));
+  for (int j = 0; j < NCH - 1; ++j) w[j] = *(const VsWord3 *)(fb + 768 * j + 12u * (uint32_t)lane);
+  w[NCH - 1] = *(const VsWord3 *)(fb + 768 * (NCH - 1) + 12u * (uint32_t)(lane < maxrem ? lane : maxrem - 1));
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     double xv[4], v[4];
@@ -127,10 +128,14 @@ __device__ __forceinline__ void vs_shared_fetch(uint32_t d0, const uint8_t *__re
   const int cls = vs_cls(d0);
   const uint8_t *fb = sbase + 16u * (size_t)vs_off(d0);
   const int32_t rem = vs_len(d0) - 64 * (cls - 1);
-  w[0] = *(const uint32_t *)(fb + 256 * (cls - 1) + 4 * (lane < rem ? lane : rem - 1));
+  // unsigned 32-bit lane offsets made opaque here: a scalar base + one VGPR per load (global_load ... saddr), instead of
+  // loop-invariant 64-bit per-lane addresses that the register file of the 16-row path has no room for
+  uint32_t l4 = 4u * (uint32_t)lane, r4 = 4u * (uint32_t)(lane < rem ? lane : rem - 1);
+  asm volatile("" : "+v"(l4), "+v"(r4));
+  w[0] = *(const uint32_t *)(fb + 256 * (cls - 1) + r4);
 #pragma unroll
   for (int j = 0; j < 5; ++j)
-    if (j < cls - 1) w[1 + j] = *(const uint32_t *)(fb + 256 * j + 4 * lane);
+    if (j < cls - 1) w[1 + j] = *(const uint32_t *)(fb + 256 * j + l4);
 }
 
 template <int NCH, int R, int WD>
@@ -198,7 +203,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   const int hl = lane & 31;
   auto hdr_load = [&](int32_t q) {   // the block's batch q, clamped to the last one (no branch around a load)
     const int32_t qq = q < nbatch ? q : (nbatch > 0 ? nbatch - 1 : 0);
-    return tb[32 * (int64_t)qq + hl];
+    uint32_t h4 = 4u * (uint32_t)hl;
+    asm volatile("" : "+v"(h4));   // as in vs_shared_fetch: scalar base + 32-bit lane offset
+    return *(const uint32_t *)((const char *)(tb + 32 * (int64_t)qq) + h4);
   };
   auto hdr = [](uint32_t hv, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)hv, k); };
   uint32_t hv1 = hdr_load(wave);
@@ -238,7 +245,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // smaller batch does not have are fillers, -1) instead of selecting it out of the descriptor's scalars.
   const int q16 = lane >> 4;
   const int rsel = 4 * (2 * ((((q16 & 1) << 1) | (q16 >> 1)) + 4 * ((lane >> 3) & 1) + 8 * ((lane >> 2) & 1)) + 1);   // ds_bpermute address of that dword
-  const uint32_t rmask = lane < 8 ? 0x7fffffffu : 0xffffffffu;     // bit 63 of row 0 is the shared-batch flag
   auto store = [&](double s, int32_t r, bool mine) {
     if (mine && r >= 0) {
       if (EPI == 0)
@@ -260,11 +266,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const bool shared = (int32_t)hdr(hv1, 1) < 0;                       // wave-uniform
     const bool sixteen = shared && (int32_t)hdr(hv1, 17) >= 0;          // a ninth row
     const bool eight = shared && !sixteen && (int32_t)hdr(hv1, 9) >= 0;  // a fifth row
-    const int32_t rid = (int32_t)((uint32_t)__builtin_amdgcn_ds_bpermute(rsel, (int)hv1) & rmask);
     const uint32_t eb = vs_off(lo[0]);
     const int cls = vs_cls(lo[0]);
     const int32_t full = cls > 0 ? 64 * (cls - 1) : 0;
     const uint8_t *fb = sbase + 16u * (size_t)eb;
+    double sres;    // the tree value of "its" row, in the lanes whose number is a multiple of mstep
+    int mstep;      // wave-uniform
     if (sixteen) {                                       // 9..16 translates
       const int32_t rem = vs_len(lo[0]) - full;
       int32_t sh[16];
@@ -281,7 +288,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         default: vs_shared<6, 16, WD>(rem, sh, lane, w, acc); break;
       }
       // lane 16 q + 8 h + 4 g holds the tree of batch row {0, 2, 1, 3}[q] + 4 h + 8 g
-      store(reduce_rows16(acc, lane), rid, (lane & 3) == 0);
+      sres = reduce_rows16(acc, lane);
+      mstep = 4;
     } else if (eight) {                                  // 5..8 translates
       const int32_t rem = vs_len(lo[0]) - full;
       int32_t sh[8];
@@ -298,44 +306,52 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         default: vs_shared<6, 8, WD>(rem, sh, lane, w, acc); break;
       }
       // lane 16 q + 8 h (q = 0..3, h = 0..1) holds the tree of batch row {0, 2, 1, 3}[q] + 4 h
-      store(reduce_rows8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], lane), rid, (lane & 7) == 0);
-    } else {
+      sres = reduce_rows8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], lane);
+      mstep = 8;
+    } else if (shared) {   // 2..4 translates
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      if (shared) {   // 2..4 translates
-        const int32_t rem = vs_len(lo[0]) - full;
-        const int32_t sh[4] = {0, (int32_t)lo[1], (int32_t)lo[2], (int32_t)lo[3]};
-        switch (cls) {
-          case 1: vs_shared<1, 4, WD>(rem, sh, lane, w, acc); break;
-          case 2: vs_shared<2, 4, WD>(rem, sh, lane, w, acc); break;
-          case 3: vs_shared<3, 4, WD>(rem, sh, lane, w, acc); break;
-          case 4: vs_shared<4, 4, WD>(rem, sh, lane, w, acc); break;
-          case 5: vs_shared<5, 4, WD>(rem, sh, lane, w, acc); break;
-          default: vs_shared<6, 4, WD>(rem, sh, lane, w, acc); break;
-        }
-      } else {
-        int32_t rem[4], maxrem = 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          rem[i] = vs_len(lo[i]) - full;
-          maxrem = rem[i] > maxrem ? rem[i] : maxrem;
-        }
-        switch (cls) {
-          case 1: vs_batch<1, WD>(rem, maxrem, lane, fb, sm, acc); break;
-          case 2: vs_batch<2, WD>(rem, maxrem, lane, fb, sm, acc); break;
-          case 3: vs_batch<3, WD>(rem, maxrem, lane, fb, sm, acc); break;
-          case 4: vs_batch<4, WD>(rem, maxrem, lane, fb, sm, acc); break;
-          case 5: vs_batch<5, WD>(rem, maxrem, lane, fb, sm, acc); break;
-          case 6: vs_batch<6, WD>(rem, maxrem, lane, fb, sm, acc); break;
-          default: break;  // class 0: empty rows
-        }
+      const int32_t rem = vs_len(lo[0]) - full;
+      const int32_t sh[4] = {0, (int32_t)lo[1], (int32_t)lo[2], (int32_t)lo[3]};
+      switch (cls) {
+        case 1: vs_shared<1, 4, WD>(rem, sh, lane, w, acc); break;
+        case 2: vs_shared<2, 4, WD>(rem, sh, lane, w, acc); break;
+        case 3: vs_shared<3, 4, WD>(rem, sh, lane, w, acc); break;
+        case 4: vs_shared<4, 4, WD>(rem, sh, lane, w, acc); break;
+        case 5: vs_shared<5, 4, WD>(rem, sh, lane, w, acc); break;
+        default: vs_shared<6, 4, WD>(rem, sh, lane, w, acc); break;
       }
-      store(reduce_rows4(acc[0], acc[1], acc[2], acc[3]), rid, (lane & 15) == 0);   // 16-lane row q: batch row {0, 2, 1, 3}[q]
+      sres = reduce_rows4(acc[0], acc[1], acc[2], acc[3]);   // 16-lane row q: batch row {0, 2, 1, 3}[q]
+      mstep = 16;
+    } else {   // plain batch: stores at once (its registers are the kernel's tightest spot, nothing is carried further)
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      int32_t rem[4], maxrem = 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rem[i] = vs_len(lo[i]) - full;
+        maxrem = rem[i] > maxrem ? rem[i] : maxrem;
+      }
+      switch (cls) {
+        case 1: vs_batch<1, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 2: vs_batch<2, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 3: vs_batch<3, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 4: vs_batch<4, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 5: vs_batch<5, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        case 6: vs_batch<6, WD>(rem, maxrem, lane, fb, sm, acc); break;
+        default: break;  // class 0: empty rows
+      }
+      store(reduce_rows4(acc[0], acc[1], acc[2], acc[3]), (int32_t)__builtin_amdgcn_ds_bpermute(rsel, (int)hv1), (lane & 15) == 0);
+      mstep = 0;
     }
     // the stream words of the wave's next shared batch (the ONE place of the loop that writes w: no copies of loaded
-    // values, which would have to wait for them), and behind them the descriptor of the batch after that
+    // values, which would have to wait for them), and behind them the descriptor of the batch after that.  The store
+    // comes LAST: vector memory operations complete in order, so a wait for anything requested after a store would
+    // also wait for the store's acknowledgement (as the round-2 kernel did, once per batch).
+    const int32_t rid = (int32_t)((uint32_t)__builtin_amdgcn_ds_bpermute(rsel, (int)hv1) &
+                                  (lane < 8 ? 0x7fffffffu : 0xffffffffu));   // bit 63 of row 0 is the shared-batch flag
     hv1 = hv2;
     if (bi + NW < nbatch && (int32_t)hdr(hv1, 1) < 0) vs_shared_fetch(hdr(hv1, 0), sbase, lane, w);
     hv2 = hdr_load(bi + 2 * NW);
+    if (mstep) store(sres, rid, (lane & (mstep - 1)) == 0);
   }
 }
 

@@ -308,7 +308,11 @@ int alfd_set_aggregates(alfd_ctx_t ctx, int level, int64_t n_fine, const int32_t
  * the aggregates of that level; rows without entries (Dirichlet / constrained unknowns) are not
  * represented on the coarse level.  Coarse operators are the Galerkin products, formed in two steps,
  * (A P) then P^T (A P), each output entry a sequential fma chain in CSR order.
- * Single rank for now: ALFD_E_UNSUPPORTED at alfd_setup on a partitioned context. */
+ * Partitioned contexts: level 0 takes the rows of P this rank owns (n_fine = its rows, GLOBAL coarse columns)
+ * together with alfd_set_aggregate_partition(ctx, 0, coarse offsets by rank) -- the coarse unknowns whose fine
+ * support lies in a rank's rows + halo of A; the prolongators of the levels below are handed over whole on every
+ * rank.  The fine level stays partitioned, levels >= 1 (and the interface patch) are replicated; the hierarchy
+ * does not depend on the partition.  Aggregates and prolongators cannot be mixed there. */
 int alfd_set_prolongator(alfd_ctx_t ctx, int level, int64_t n_fine, int64_t n_coarse, const int64_t *row_ptr,
                          const int32_t *col, const double *val);
 /* Multi-rank: agg[] holds this rank's unknowns of level l and GLOBAL coarse ids; the coarse
