@@ -340,7 +340,7 @@ def test_partitioned_interface_problems_match_oracle_emulation(built, name, worl
         assert np.allclose(xs, ox[b], rtol=1e-8, atol=1e-9 * max(np.abs(ox[b]).max(), 1e-30))
 
 
-@pytest.mark.parametrize("world,patch", [(2, True), (3, True), (2, False)])
+@pytest.mark.parametrize("world,patch", [(2, True), (3, True), (2, False), (4, True)])
 def test_partitioned_geometric_multigrid_matches_oracle_emulation(built, world, patch):
     """The round-3 inner preconditioner on a row-partitioned context: CSR prolongators (level 0: each rank's rows, the
     levels below whole), fine level partitioned, the coarse hierarchy and the interface patch REPLICATED and built
