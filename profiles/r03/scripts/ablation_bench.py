@@ -1,6 +1,6 @@
 """Times the A-SpMV (N = 74, mesh bricks 16x4x1) with an alternative build of the library: ablation experiments."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))   # repo root
 from fictitious_domain_al_preconditioners_amd import problems, solver, _abi
 if len(sys.argv) > 1 and sys.argv[1] != "base":
     solver.LIB_PATH = os.path.abspath(sys.argv[1])
