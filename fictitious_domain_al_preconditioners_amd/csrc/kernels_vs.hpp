@@ -272,6 +272,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint8_t *fb = sbase + 16u * (size_t)eb;
     double sres;    // the tree value of "its" row, in the lanes whose number is a multiple of mstep
     int mstep;      // wave-uniform
+    uint32_t n0, n1;   // row 0 of the NEXT batch's descriptor (offset | count | class, row | shared flag)
     if (sixteen) {                                       // 9..16 translates
       const int32_t rem = vs_len(lo[0]) - full;
       int32_t sh[16];
@@ -339,6 +340,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
         case 6: vs_batch<6, WD>(rem, maxrem, lane, fb, sm, acc); break;
         default: break;  // class 0: empty rows
       }
+      // the next descriptor is read BEFORE the store: after it, the wait that makes hv2 readable would also wait for
+      // the store's acknowledgement, and only then would the next batch's loads go out (two round trips in a row)
+      n0 = hdr(hv2, 0);
+      n1 = hdr(hv2, 1);
       store(reduce_rows4(acc[0], acc[1], acc[2], acc[3]), (int32_t)__builtin_amdgcn_ds_bpermute(rsel, (int)hv1), (lane & 15) == 0);
       mstep = 0;
     }
@@ -346,10 +351,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // values, which would have to wait for them), and behind them the descriptor of the batch after that.  The store
     // comes LAST: vector memory operations complete in order, so a wait for anything requested after a store would
     // also wait for the store's acknowledgement (as the round-2 kernel did, once per batch).
-    const int32_t rid = (int32_t)((uint32_t)__builtin_amdgcn_ds_bpermute(rsel, (int)hv1) &
-                                  (lane < 8 ? 0x7fffffffu : 0xffffffffu));   // bit 63 of row 0 is the shared-batch flag
+    int32_t rid = -1;
+    if (mstep) {
+      rid = (int32_t)((uint32_t)__builtin_amdgcn_ds_bpermute(rsel, (int)hv1) &
+                      (lane < 8 ? 0x7fffffffu : 0xffffffffu));   // bit 63 of row 0 is the shared-batch flag
+      n0 = hdr(hv2, 0);
+      n1 = hdr(hv2, 1);
+    }
     hv1 = hv2;
-    if (bi + NW < nbatch && (int32_t)hdr(hv1, 1) < 0) vs_shared_fetch(hdr(hv1, 0), sbase, lane, w);
+    if (bi + NW < nbatch && (int32_t)n1 < 0) vs_shared_fetch(n0, sbase, lane, w);
     hv2 = hdr_load(bi + 2 * NW);
     if (mstep) store(sres, rid, (lane & (mstep - 1)) == 0);
   }
