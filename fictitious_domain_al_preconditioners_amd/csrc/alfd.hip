@@ -5089,6 +5089,10 @@ int alfd_comm_init(alfd_ctx_t ctx, int rank, int nranks, const void *id, size_t 
   std::memcpy(&uid, id, sizeof(uid));
   if (ncclCommInitRank(&ctx->nccl, nranks, uid, rank) != ncclSuccess)
     return ctx->err = "ncclCommInitRank failed", ALFD_E_COMM;
+  if (rank == 0) {   // which RCCL this process resolved (the library links $(ROCM)/lib/librccl, torch bundles its own copy)
+    int v = 0;
+    if (ncclGetVersion(&v) == ncclSuccess) std::fprintf(stderr, "[alfd] RCCL version %d, %d ranks\n", v, nranks);
+  }
   return ALFD_OK;
 }
 
