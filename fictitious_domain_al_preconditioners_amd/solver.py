@@ -545,20 +545,48 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_bloc
     reference's diagonal choices: W^-1 = 1/M_ii^2 (stokes...:976-978), lumped
     pressure mass (stokes...:946-954).  aggregates: [(agg, n_coarse), ...] for
     ALFD_PREC_MULTILEVEL (problems.geometric_aggregates), or [(Csr P, n_coarse), ...]
-    (problems.tensor_prolongators).  row_blocks: (block_ptr, rows)
+    (problems.tensor_prolongators), or a zero-argument callable returning either (evaluated on a helper
+    thread while the operators are uploaded).  row_blocks: (block_ptr, rows)
     for the SpMV on A (Context.set_row_blocks, e.g. problems.brick_row_blocks)."""
     if row_blocks is not None:
         ctx.set_row_blocks(_abi.A, *row_blocks)
-    for level, entry in enumerate(aggregates or []):
-        agg, nc = entry[0], entry[1]
-        if hasattr(agg, "row_ptr"):                       # a CSR prolongator (problems.tensor_prolongators)
-            ctx.set_prolongator(level, agg)
-            if len(entry) > 2 and entry[2] is not None:   # partitioned context: coarse offsets by rank (partition.local_prolongators)
+
+    def set_hierarchy(levels):
+        for level, entry in enumerate(levels or []):
+            agg, nc = entry[0], entry[1]
+            if hasattr(agg, "row_ptr"):                       # a CSR prolongator (problems.tensor_prolongators)
+                ctx.set_prolongator(level, agg)
+                if len(entry) > 2 and entry[2] is not None:   # partitioned context: coarse offsets by rank (partition.local_prolongators)
+                    ctx.set_aggregate_partition(level, entry[2])
+                continue
+            ctx.set_aggregates(level, agg, nc)
+            if len(entry) > 2 and entry[2] is not None:      # (agg_local, n_coarse_global, coarse_offsets)
                 ctx.set_aggregate_partition(level, entry[2])
-            continue
-        ctx.set_aggregates(level, agg, nc)
-        if len(entry) > 2 and entry[2] is not None:      # (agg_local, n_coarse_global, coarse_offsets)
-            ctx.set_aggregate_partition(level, entry[2])
+
+    # aggregates may be a zero-argument callable: the transfer operators are then built on a helper thread while this one
+    # uploads the operators (the library's format planning runs outside the interpreter lock), and handed over before setup
+    pending = None
+    if callable(aggregates):
+        import threading
+        box = {}
+
+        def work():
+            try:
+                box["levels"] = aggregates()
+            except BaseException as e:   # noqa: BLE001  (re-raised on the caller's thread)
+                box["error"] = e
+        pending = threading.Thread(target=work)
+        pending.start()
+    else:
+        set_hierarchy(aggregates)
+
+    def finish_hierarchy():
+        if pending is not None:
+            pending.join()
+            if "error" in box:
+                raise box["error"]
+            set_hierarchy(box["levels"])
+
     ctx.set_matrix(_abi.A, pb.mats["A"])
     # C before CT (and B before BT): an explicitly uploaded transpose is left alone, otherwise alfd_set_matrix(CT) would
     # first derive C on the host (a single-threaded transpose + upload) only to see it replaced by the next call
@@ -568,6 +596,7 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_bloc
         # rational branch (immersed_laplace.cc:585-631): K, Ct, immersed stiffness and mass
         ctx.set_matrix(_abi.M, pb.mats["M"])
         ctx.set_matrix(_abi.KIMM, pb.mats["K"])
+        finish_hierarchy()
         ctx.configure(cfg)
         ctx.setup(pb.block_sizes)
         return ctx
@@ -576,6 +605,7 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_bloc
         ctx.set_matrix(_abi.A2, pb.mats["A2"])
         ctx.set_matrix(_abi.M, pb.mats["M"])
         ctx.set_diag(_abi.INVW, pb.inv_w_diag_of_mass_squared())
+        finish_hierarchy()
         ctx.configure(cfg)
         ctx.setup(pb.block_sizes)
         return ctx
@@ -587,6 +617,7 @@ def upload_problem(ctx: Context, pb, cfg: _abi.Config, aggregates=None, row_bloc
         ctx.set_matrix(_abi.BT, pb.mats["Bt"])
         ctx.set_matrix(_abi.MP, pb.mats["Mp"])
         ctx.set_diag(_abi.MP_LUMPED_INV, pb.mp_lumped_inv())
+    finish_hierarchy()
     ctx.configure(cfg)
     ctx.setup(pb.block_sizes)
     return ctx
