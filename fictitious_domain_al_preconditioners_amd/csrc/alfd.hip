@@ -795,6 +795,46 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
   return ALFD_OK;
 }
 
+// A short-row operator that took the batch-major form (spmv_vss_kernel) also has the windowed group kernel to fall back
+// on, and which of the two is faster depends on the operator: the 27-point stencils of cfg 2 run 3x faster batch-major,
+// the 9.9 M x 0.42 M gradient block Bt of the Stokes system (15 entries per row, few translates) 1.5x SLOWER (0.66 against
+// 0.44 ms).  Large operators are therefore timed once at upload, five launches of each on a zero vector, and keep the
+// faster form; results do not depend on the choice (same canonical sums).
+static int pick_short_row_format(alfd_ctx *ctx, DevCsr &m) {
+  if (!m.vs.on || m.vs.L == 64 || !m.win || m.nnz < 20000000 || ctx->vi_off || !ctx->vs_enable) return ALFD_OK;
+  double *x = nullptr, *y = nullptr;
+  const int64_t nx = std::max<int64_t>(ctx->nranks > 1 && !m.rep ? m.n_local_cols : m.ncols, 1);
+  HIPC(hipMalloc((void **)&x, nx * sizeof(double)));
+  HIPC(hipMalloc((void **)&y, std::max<int64_t>(m.nrows, 1) * sizeof(double)));
+  HIPC(hipMemsetAsync(x, 0, nx * sizeof(double), ctx->stream));
+  hipEvent_t e0, e1;
+  HIPC(hipEventCreate(&e0));
+  HIPC(hipEventCreate(&e1));
+  float t[2] = {0.f, 0.f};
+  bool ok = true;
+  for (int f = 0; f < 2 && ok; ++f) {
+    for (int it = 0; it < 6 && ok; ++it) {   // the first launch of each form is a warm-up
+      if (it == 1) hipEventRecord(e0, ctx->stream);
+      ok = f == 0 ? launch_vs(ctx, m, x, y, 0, 0.0, nullptr, nullptr) : launch_window_RU(ctx, m, x, y, 0, 0.0, nullptr, nullptr);
+    }
+    hipEventRecord(e1, ctx->stream);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&t[f], e0, e1);
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(x);
+  hipFree(y);
+  HIPC(hipGetLastError());
+  if (ok && t[1] < 0.9f * t[0]) {
+    m.vs.on = false;
+    if (ctx->cfg.log_level > 0 || std::getenv("ALFD_LOG_UPLOAD"))
+      std::fprintf(stderr, "[alfd] short-row operator (%lld rows, %lld nnz): windowed group kernel %.3f ms, batch-major %.3f ms per launch "
+                   "-> batch-major form dropped\n", (long long)m.nrows, (long long)m.nnz, t[1] / 5.0, t[0] / 5.0);
+  }
+  return ALFD_OK;
+}
+
 static int spmv(alfd_ctx *ctx, int slot, const double *x, double *y, int epi, double alpha = 0.0,
                 const double *d = nullptr, double *y2 = nullptr) {
   DevCsr &m = ctx->mat[slot];
@@ -2874,6 +2914,7 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
     if (copy_job.rc != hipSuccess) return ctx->err = hipGetErrorString(copy_job.rc), ALFD_E_HIP;
   }
   m.present = true;
+  RC(pick_short_row_format(ctx, m));
   return ALFD_OK;
 }
 
