@@ -2039,6 +2039,7 @@ struct VsPlan {
 };
 
 constexpr int kVsBatchRows = 16;   // rows a batch descriptor names (16 x uint64 = 128 bytes)
+constexpr int kVsRefineW = 2048;   // window a block halved for its window may keep (slots): 8 workgroups per CU; B at N = 74: 0.129 ms (4096: 0.138, 1536: 0.170, general kernel 0.414)
 struct VsBatch {
   int cls, nreal, id[kVsBatchRows];   // plain: up to 4 rows; shared: up to 16
   bool shared;                        // the rows are translates of one another: one template + a window shift per row
@@ -2046,50 +2047,71 @@ struct VsBatch {
 };
 
 // x window of a row block: maximal runs of used columns, gaps shorter than GAP bridged, cut into pieces
-// of at most 64 slots (one wave-load each).  pos[c - clo] = window slot of column c.
+// of at most 64 slots (one wave-load each).  slot(c) = window slot of column c.
 struct VsWindow {
   int32_t clo = 0, W = 0, nseg = 0;
-  std::vector<int32_t> pos;
-  std::vector<uint8_t> mark;
+  // the window as runs of consecutive columns: run i holds columns run_col[i] .. run_col[i] + run_len[i] - 1 in the
+  // slots run_slot[i] ..  (sparse: a block of an operator whose rows reach far -- the divergence block of a Taylor-Hood
+  // pair -- spans 300 k columns with 2 k of them used; dense per-column tables made planning such operators cost more
+  // than planning A)
+  std::vector<int32_t> run_col, run_slot, run_len;
+  std::vector<uint8_t> mark;       // scratch, all zero between calls, grown on demand
+  std::vector<int32_t> ucol;       // scratch
+  int32_t slot(int32_t c) const {  // window slot of a column of the block
+    size_t lo = 0, hi = run_col.size();
+    while (hi - lo > 1) {
+      const size_t mid = (lo + hi) / 2;
+      if (run_col[mid] <= c) lo = mid;
+      else hi = mid;
+    }
+    return run_slot[lo] + (c - run_col[lo]);
+  }
 };
 static bool vs_window(const std::vector<int32_t> &rows, const int64_t *rp, const int32_t *col, int GAP, int maxW,
                       VsWindow &w, std::vector<int32_t> *seg_col, std::vector<int32_t> *seg_off) {
-  int32_t clo = INT32_MAX, chi = -1;
+  w.ucol.clear();
   for (int32_t r : rows)
     for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
-      clo = std::min(clo, col[k]);
-      chi = std::max(chi, col[k]);
+      const int32_t c = col[k];
+      if ((size_t)c >= w.mark.size()) w.mark.resize((size_t)c + 1 + w.mark.size() / 2, 0);
+      if (!w.mark[c]) {
+        w.mark[c] = 1;
+        w.ucol.push_back(c);
+      }
     }
-  const int64_t range = chi < 0 ? 0 : (int64_t)chi - clo + 1;
-  if (range > (int64_t)(1 << 24)) return false;
-  w.clo = chi < 0 ? 0 : clo;
-  w.mark.assign(range, 0);
-  for (int32_t r : rows)
-    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) w.mark[col[k] - clo] = 1;
-  w.pos.assign(range, -1);
+  for (int32_t c : w.ucol) w.mark[c] = 0;
+  std::sort(w.ucol.begin(), w.ucol.end());
+  w.clo = w.ucol.empty() ? 0 : w.ucol.front();
+  w.run_col.clear();
+  w.run_slot.clear();
+  w.run_len.clear();
   w.W = 0;
   w.nseg = 0;
-  int64_t c = 0;
-  while (c < range) {
-    if (!w.mark[c]) {
-      ++c;
-      continue;
-    }
-    int64_t e = c, last = c;
-    while (e < range) {
-      if (w.mark[e]) last = e;
-      else if (e - last >= GAP) break;
-      ++e;
-    }
-    for (int64_t q0 = c; q0 <= last; q0 += 64) {
+  size_t i = 0;
+  while (i < w.ucol.size()) {
+    const int32_t c = w.ucol[i];
+    int32_t last = c;
+    size_t j = i + 1;
+    while (j < w.ucol.size() && w.ucol[j] - last <= GAP) last = w.ucol[j++];   // gaps shorter than GAP are bridged
+    const int32_t len = last - c + 1;
+    for (int32_t q0 = 0; q0 < len; q0 += 64) {   // pieces of at most 64 slots (one wave-load each)
       if (seg_col) {
-        seg_col->push_back((int32_t)(clo + q0));
-        seg_off->push_back(w.W + (int32_t)(q0 - c));
+        seg_col->push_back(c + q0);
+        seg_off->push_back(w.W + q0);
       }
       ++w.nseg;
     }
-    for (int64_t q = c; q <= last; ++q) w.pos[q] = w.W++;
-    c = last + 1;
+    w.run_col.push_back(c);
+    w.run_slot.push_back(w.W);
+    w.run_len.push_back(len);
+    w.W += len;
+    if (w.W > 4096 && !seg_col) return false;   // hopeless already (the planner's callers pass no segment lists when probing)
+    i = j;
+  }
+  if (w.run_col.empty()) {
+    w.run_col.push_back(0);
+    w.run_slot.push_back(0);
+    w.run_len.push_back(0);
   }
   return w.W <= maxW && w.W <= 4096;
 }
@@ -2110,13 +2132,13 @@ static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, cons
     if (n > kVsMaxLen) return false;
     len[i] = n;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
-    const int32_t p0 = n ? w.pos[col[k0] - w.clo] : 0;
+    const int32_t p0 = n ? w.slot(col[k0]) : 0;
     first[i] = p0;
     for (int64_t k = 0; k < n; ++k) {
       uint64_t bits;
       std::memcpy(&bits, &val[k0 + k], 8);
       h = (h ^ bits) * 0xff51afd7ed558ccdull;
-      h = (h ^ (uint64_t)(uint32_t)(w.pos[col[k0 + k] - w.clo] - p0)) * 0xc4ceb9fe1a85ec53ull;
+      h = (h ^ (uint64_t)(uint32_t)(w.slot(col[k0 + k]) - p0)) * 0xc4ceb9fe1a85ec53ull;
       h ^= h >> 29;
     }
     key[i] = h;
@@ -2126,7 +2148,7 @@ static bool vs_batches(const std::vector<int32_t> &rows, const int64_t *rp, cons
     const int64_t ka = rp[rows[a]], kb = rp[rows[b]];
     for (int64_t k = 0; k < len[a]; ++k) {
       if (std::memcmp(&val[ka + k], &val[kb + k], 8) != 0) return false;
-      if (w.pos[col[ka + k] - w.clo] - first[a] != w.pos[col[kb + k] - w.clo] - first[b]) return false;
+      if (w.slot(col[ka + k]) - first[a] != w.slot(col[kb + k]) - first[b]) return false;
     }
     return true;
   };
@@ -2265,16 +2287,92 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
   pl.wide = wide;
   pl.nb_in = nb_in > 0 ? nb_in : (nrows + RB - 1) / RB;
   if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, nb_in, bptr_in, brows_in, r_ptr, r_rows, kVsMaxRows, max_dict)) return;
-  const int64_t *bptr = r_ptr.data();
-  const int32_t *brows = r_rows.data();
-  const int64_t nb = (int64_t)r_ptr.size() - 1;
-  if (nb == 0 || nb > 2147483000LL) return;
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  // pass 1: windows, batches (kept), stream extents
-  std::vector<std::vector<VsBatch>> batches(nb);
-  std::vector<int64_t> blk_units(nb, 0);
-  std::atomic<bool> bad(false);
+  std::vector<std::vector<VsBatch>> batches;
+  std::vector<int64_t> blk_units;
+  std::atomic<bool> bad(false), too_wide(false);
   std::atomic<int64_t> n_shared_nnz(0);
+  int64_t nb = 0;
+  const int64_t *bptr = nullptr;
+  const int32_t *brows = nullptr;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    if (attempt == 1) {
+      // cheap first: how often do a few sample blocks have to be halved?  Split every block that often, untested (the
+      // pass below tests all of them; what still does not fit goes through the exact refinement of attempt 2)
+      if (!too_wide) return;
+      int k = 0;
+      std::vector<int32_t> rows;
+      VsWindow w;
+      for (int64_t b : {(int64_t)0, nb / 2, nb - 1}) {
+        int64_t len = bptr[b + 1] - bptr[b];
+        int kb = 0;
+        for (; len > 1; ++kb, len = (len + 1) / 2) {
+          rows.assign(brows + bptr[b], brows + bptr[b] + len);
+          if (vs_window(rows, rp, col, GAP, std::min(maxW, kVsRefineW), w, nullptr, nullptr)) break;
+        }
+        k = std::max(k, kb);
+      }
+      if (k == 0) continue;   // the samples fit: straight to the exact refinement
+      std::vector<int64_t> np(1, 0);
+      for (int64_t b = 0; b < nb; ++b) {
+        const int64_t a = bptr[b], len = bptr[b + 1] - a, pieces = std::min<int64_t>((int64_t)1 << k, std::max<int64_t>(len, 1));
+        for (int64_t q = 1; q <= pieces; ++q)
+          if (a + len * q / pieces > np.back()) np.push_back(a + len * q / pieces);
+      }
+      r_ptr.swap(np);
+      bad = false;
+      too_wide = false;
+      n_shared_nnz = 0;
+    }
+    if (attempt == 2) {
+      // A block's x window did not fit the LDS budget (operators whose rows reach far, e.g. the divergence block B of a
+      // Taylor-Hood pair: 96 pressure rows touch 15 000 velocity columns): halve such blocks until their windows fit.
+      // Only paid by operators that need it -- the first attempt is the plan of everything else.
+      if (!too_wide) return;
+      std::vector<std::vector<int64_t>> t_sizes(T);
+      std::atomic<bool> hopeless(false);
+      const int64_t nb0 = nb;
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t]() {
+          std::vector<int32_t> rows;
+          VsWindow w;
+          std::vector<std::pair<int64_t, int64_t>> stack;
+          for (int64_t b = nb0 * t / T; b < nb0 * (t + 1) / T && !hopeless; ++b) {
+            stack.clear();
+            stack.emplace_back(bptr[b], bptr[b + 1]);
+            while (!stack.empty() && !hopeless) {   // depth-first, left half first: pieces come out in row-list order
+              const auto [a, e] = stack.back();
+              stack.pop_back();
+              rows.assign(brows + a, brows + e);
+              if (vs_window(rows, rp, col, GAP, std::min(maxW, kVsRefineW), w, nullptr, nullptr)) {
+                t_sizes[t].push_back(e - a);
+              } else if (e - a <= 1) {
+                hopeless = true;
+              } else {
+                const int64_t mid = a + (e - a) / 2;
+                stack.emplace_back(mid, e);
+                stack.emplace_back(a, mid);
+              }
+            }
+          }
+        });
+      for (auto &x : th) x.join();
+      if (hopeless) return;
+      std::vector<int64_t> np(1, 0);
+      for (int t = 0; t < T; ++t)
+        for (int64_t sz : t_sizes[t]) np.push_back(np.back() + sz);
+      r_ptr.swap(np);
+      bad = false;
+      n_shared_nnz = 0;
+    }
+  bptr = r_ptr.data();
+  brows = r_rows.data();
+  nb = (int64_t)r_ptr.size() - 1;
+  if (nb == 0 || nb > 2147483000LL) return;
+  // pass 1: windows, batches (kept), stream extents
+  batches.assign(nb, std::vector<VsBatch>());
+  blk_units.assign(nb, 0);
   {
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t)
@@ -2284,8 +2382,12 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
         int64_t sh = 0;
         for (int64_t b = nb * t / T; b < nb * (t + 1) / T && !bad; ++b) {
           rows.assign(brows + bptr[b], brows + bptr[b + 1]);
-          if (rows.size() > (size_t)kVsMaxRows || !vs_window(rows, rp, col, GAP, maxW, w, nullptr, nullptr) ||
-              !vs_batches(rows, rp, col, val, w, batches[b], share)) {
+          if (rows.size() <= (size_t)kVsMaxRows && !vs_window(rows, rp, col, GAP, maxW, w, nullptr, nullptr)) {
+            too_wide = true;
+            bad = true;
+            break;
+          }
+          if (rows.size() > (size_t)kVsMaxRows || !vs_batches(rows, rp, col, val, w, batches[b], share)) {
             bad = true;
             break;
           }
@@ -2300,6 +2402,8 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
         n_shared_nnz += sh;
       });
     for (auto &x : th) x.join();
+  }
+    if (!bad) break;
   }
   if (bad) return;
   pl.nb = nb;
@@ -2363,7 +2467,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
               if (keys[h] == bits) break;
               h = (h + 1) & (kTab - 1);
             }
-            return ((int64_t)ids[h] << code_shift) | ((int64_t)w.pos[col[k] - w.clo] << 3);
+            return ((int64_t)ids[h] << code_shift) | ((int64_t)w.slot(col[k]) << 3);
           };
           for (size_t q = 0; q < bts.size() && !bad; ++q) {
             const VsBatch &bt = bts[q];
@@ -2472,13 +2576,13 @@ static void plan_vss(int64_t nrows, int L, const int64_t *rp, const int32_t *col
             if (n > (int64_t)kVssMaxClass * L) { bad = true; break; }
             len[i] = n;
             uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
-            const int32_t p0 = n ? w.pos[col[k0] - w.clo] : 0;
+            const int32_t p0 = n ? w.slot(col[k0]) : 0;
             first[i] = p0;
             for (int64_t k = 0; k < n; ++k) {
               uint64_t bits;
               std::memcpy(&bits, &val[k0 + k], 8);
               h = (h ^ bits) * 0xff51afd7ed558ccdull;
-              h = (h ^ (uint64_t)(uint32_t)(w.pos[col[k0 + k] - w.clo] - p0)) * 0xc4ceb9fe1a85ec53ull;
+              h = (h ^ (uint64_t)(uint32_t)(w.slot(col[k0 + k]) - p0)) * 0xc4ceb9fe1a85ec53ull;
               h ^= h >> 29;
             }
             key[i] = h;
@@ -2489,7 +2593,7 @@ static void plan_vss(int64_t nrows, int L, const int64_t *rp, const int32_t *col
             const int64_t ka = rp[rows[a]], kc = rp[rows[c]];
             for (int64_t k = 0; k < len[a]; ++k) {
               if (std::memcmp(&val[ka + k], &val[kc + k], 8) != 0) return false;
-              if (w.pos[col[ka + k] - w.clo] - first[a] != w.pos[col[kc + k] - w.clo] - first[c]) return false;
+              if (w.slot(col[ka + k]) - first[a] != w.slot(col[kc + k]) - first[c]) return false;
             }
             return true;
           };
@@ -2593,7 +2697,7 @@ static void plan_vss(int64_t nrows, int L, const int64_t *rp, const int32_t *col
                 h = (h + 1) & (kTab - 1);
               }
               if (bad) break;
-              const uint32_t f = ((uint32_t)ids[h] << 15) | ((uint32_t)w.pos[col[k0 + k] - w.clo] << 3);
+              const uint32_t f = ((uint32_t)ids[h] << 15) | ((uint32_t)w.slot(col[k0 + k]) << 3);
               std::memcpy(sp + 16 * (size_t)eoff + 4 * (size_t)k, &f, 4);
             }
             dst[0] = (uint64_t)eoff | ((uint64_t)n << 20) | ((uint64_t)bt.cls << 29) | ((uint64_t)bt.nreal << 32);
