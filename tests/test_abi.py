@@ -122,6 +122,24 @@ def test_host_stream_plan_decodes_back():
     assert not solver.host_stream_plan(rnd)["ok"]
 
 
+def test_host_stream_plan_splits_blocks_with_wide_windows():
+    """An operator whose rows reach far -- the divergence block B of a Taylor-Hood pair: 96 consecutive pressure rows
+    touch far more than 4096 velocity columns -- keeps the batch-major form: blocks are split until their x window
+    fits (sampled split factor, exact halving as the fall-back), 16 translate rows per shared batch; the plan decodes
+    back to the CSR it was made from.  No GPU involved."""
+    from fictitious_domain_al_preconditioners_amd import problems
+    pb = problems.stokes3d_sphere(n_cells=12, immersed_refine=1)
+    b = pb.mats["B"]
+    info = solver.host_stream_plan(b)
+    assert info["ok"] and info["decode_mismatches"] == 0 and info["rows_covered"] == b.nrows, info
+    assert info["max_window"] <= 2048 and info["max_rows"] < 96            # split for the window, to 8 workgroups per CU
+    assert info["shared_nnz"] > 0.6 * b.nnz and info["stream_bytes"] < 3.0 * b.nnz   # a 12^3 grid is mostly boundary
+    a = pb.mats["A"]
+    bricks = solver.host_stream_plan(a, blocks=problems.brick_row_blocks(pb.params, (16, 4, 1)))
+    assert bricks["ok"] and bricks["decode_mismatches"] == 0 and bricks["rows_covered"] == a.nrows
+    assert bricks["shared_nnz"] > 0.8 * a.nnz      # 16-row batches included (twelve row types x 16 translates per interior brick)
+
+
 def test_host_stream_plan_short_rows_decodes_back():
     """The short-row batch-major form (spmv_vss_kernel: one stored template row per batch of translate rows)
     planned on the host decodes back to the CSR, for L = 32 / 16 / 8 lanes per row; nearly every entry of a

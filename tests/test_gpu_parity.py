@@ -176,6 +176,29 @@ def test_batch_major_short_rows_bitwise(built, kind):
         ctx.close()
 
 
+def test_divergence_and_gradient_blocks_bitwise(built):
+    """B and Bt of the Stokes system at a size where the storage formats apply (N = 36: 50 653 pressure rows): B takes the
+    batch-major form with blocks split for their x windows, Bt (short rows) whichever of its two forms the upload-time
+    timing keeps; both equal the oracle's canonical SpMV bit for bit, in every epilogue the solver uses."""
+    pb = problems.stokes3d_sphere(n_cells=36, immersed_refine=2)
+    ctx = solver.Context(0)
+    try:
+        for name, slot in (("B", _abi.B), ("Bt", _abi.BT)):
+            m = pb.mats[name]
+            ctx.set_matrix(slot, m)
+            info = ctx.matrix_info(slot)
+            if name == "B":
+                assert info["batch_major"] == 1 and info["streamed_bytes"] < 2.5 * m.nnz, info
+            x = _rng_vec(m.ncols, 21)
+            y0 = _rng_vec(m.nrows, 22)
+            for mode in (0, 1):
+                got, lanes = ctx.spmv(slot, x, y0, mode=mode, alpha=0.625)
+                ref, olanes = oracle.spmv(m, x, y0 if mode else None, mode=mode, alpha=0.625)
+                assert lanes == olanes and np.array_equal(got, ref), (name, mode)
+    finally:
+        ctx.close()
+
+
 def test_spmv_every_kernel_family_bitwise(built):
     """Matrices that exercise each lanes-per-row kernel, the sparse-row form, the
     streaming kernel and the LDS-windowed kernel (>= 512 row blocks), incl.
