@@ -5208,6 +5208,7 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (const char *e = std::getenv("ALFD_ML_GPU_GALERKIN")) ctx->ml_gpu_galerkin = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_LEVELS")) ctx->vi_levels = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_BATCH_MAJOR")) ctx->vs_enable = std::atoi(e);
+  if (const char *e = std::getenv("ALFD_SPMV_BATCH_MAJOR_ROWS")) ctx->vs_RB = std::max(4, std::min(kVsMaxRows, std::atoi(e)));
   if (const char *e = std::getenv("ALFD_SPMV_VI_XCD")) ctx->vi_xcd = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_VI_BATCHED")) ctx->vi_batched = std::atoi(e);
   if (const char *e = std::getenv("ALFD_SPMV_WINDOW_RB_VI")) ctx->win_RB_vi = std::atoi(e);
