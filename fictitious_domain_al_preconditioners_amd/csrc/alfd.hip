@@ -110,6 +110,12 @@ struct DevCsr {
     uint64_t *tab = nullptr;
     int32_t *cnt = nullptr, *seg_begin = nullptr, *blkW = nullptr, *seg_col = nullptr,
             *seg_off = nullptr, *doff = nullptr, *dn = nullptr;
+    // long rows (spmv_vs_kernel): everything a block needs first is addressable from its index alone -- an 8-dword
+    // header {batches, window slots, segments, dictionary size, dictionary offset, stream offset lo / hi, 0} and the
+    // segment table with a fixed stride per block ((column, slot) pairs) -- so that the x window is requested after ONE
+    // dependent round trip instead of two (header -> segment table -> x)
+    int32_t *hdrb = nullptr, *segx = nullptr;
+    int32_t seg_stride = 0;
     double *dict = nullptr;
   } vs;
   // bytes the kernel in use moves per launch (format bytes, x read once)
@@ -720,9 +726,8 @@ static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y
   if (v.L == 8) return launch_vss<8>(ctx, m, x, y, epi, alpha, d, y2), true;
   const int NW = ctx->vs_NW;
   const size_t lds = (size_t)(v.wide ? VsFmt<1>::kWinOff : VsFmt<0>::kWinOff) + (size_t)v.maxW * sizeof(double);
-#define ALFD_VS_ARGS                                                                                          \
-  v.stream, v.sb, v.tab, v.cnt, v.stride, v.seg_begin, v.blkW, v.seg_col, v.seg_off, v.doff, v.dn, v.dict, x, \
-      m.halo, m.n_local_cols, y, alpha, d, y2, ctx->vs_xcd
+#define ALFD_VS_ARGS \
+  v.stream, v.tab, v.stride, v.hdrb, v.segx, v.seg_stride, v.dict, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->vs_xcd
 #define ALFD_VS(EPI, NWV)                                                                                        \
   do {                                                                                                           \
     if (v.wide) /* 10-bit codes: one instantiation per epilogue (4 waves) */                                    \
@@ -2773,18 +2778,36 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
   }
   if (!pl.ok) return ALFD_OK;
   DevCsr::Vs &v = m.vs;
+  // block headers and the fixed-stride segment table (the kernel reads one segment past a block's last, and its first
+  // round of 8 x 4 segments unconditionally; the descriptor table is read up to 16 batches past a block's last)
+  int32_t max_nseg = 0;
+  for (int64_t b = 0; b < pl.nb; ++b) max_nseg = std::max(max_nseg, pl.seg_begin[b + 1] - pl.seg_begin[b]);
+  const int32_t S = std::max(max_nseg + 1, 33);
+  if ((double)pl.nb * S * 8.0 > 2.0e9) return ALFD_OK;   // a block with thousands of window pieces: not this format
+  std::vector<int32_t> hdrb((size_t)pl.nb * 8, 0), segx((size_t)pl.nb * S * 2 + 16, 0);   // + the reads past the last block
+  for (int64_t b = 0; b < pl.nb; ++b) {
+    const int32_t s0 = pl.seg_begin[b], ns = pl.seg_begin[b + 1] - s0;
+    int32_t *h = &hdrb[(size_t)b * 8];
+    h[0] = pl.cnt[b];
+    h[1] = pl.blkW[b];
+    h[2] = ns;
+    h[3] = pl.dn[b];
+    h[4] = pl.doff[b];
+    h[5] = (int32_t)(uint32_t)((uint64_t)pl.sb[b] & 0xffffffffull);
+    h[6] = (int32_t)((uint64_t)pl.sb[b] >> 32);
+    for (int32_t q = 0; q < ns; ++q) {
+      segx[((size_t)b * S + q) * 2] = pl.seg_col[s0 + q];
+      segx[((size_t)b * S + q) * 2 + 1] = pl.seg_off[s0 + q];
+    }
+  }
+  pl.tab.resize(pl.tab.size() + (size_t)16 * kVsBatchRows, 0);
   RC(upload_vec(ctx, m, &v.stream, pl.stream));
-  RC(upload_vec(ctx, m, &v.sb, pl.sb));
   RC(upload_vec(ctx, m, &v.tab, pl.tab));
-  RC(upload_vec(ctx, m, &v.cnt, pl.cnt));
-  RC(upload_vec(ctx, m, &v.seg_begin, pl.seg_begin));
-  RC(upload_vec(ctx, m, &v.blkW, pl.blkW));
-  RC(upload_vec(ctx, m, &v.seg_col, pl.seg_col));
-  RC(upload_vec(ctx, m, &v.seg_off, pl.seg_off));
-  RC(upload_vec(ctx, m, &v.doff, pl.doff));
-  RC(upload_vec(ctx, m, &v.dn, pl.dn));
+  RC(upload_vec(ctx, m, &v.hdrb, hdrb));
+  RC(upload_vec(ctx, m, &v.segx, segx));
   RC(upload_vec(ctx, m, &v.dict, pl.dict));
   HIPC(hipStreamSynchronize(ctx->stream));
+  v.seg_stride = S;
   v.nb = pl.nb;
   v.nseg = (int64_t)pl.seg_col.size();
   v.stream_bytes = (int64_t)pl.stream.size() - 4096;

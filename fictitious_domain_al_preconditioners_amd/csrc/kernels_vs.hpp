@@ -175,10 +175,8 @@ __device__ __forceinline__ void vs_shared(int32_t rem, const int32_t (&sh)[R], i
 
 template <int EPI, int TAG, int NW, int WD = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_vs_kernel(
-    const uint8_t *__restrict__ stream, const int64_t *__restrict__ sb, const uint64_t *__restrict__ tab,
-    const int32_t *__restrict__ cnt, int32_t stride, const int32_t *__restrict__ blk_seg_begin,
-    const int32_t *__restrict__ blk_W, const int32_t *__restrict__ seg_col, const int32_t *__restrict__ seg_off,
-    const int32_t *__restrict__ blk_dict_off, const int32_t *__restrict__ blk_dict_n,
+    const uint8_t *__restrict__ stream, const uint64_t *__restrict__ tab, int32_t stride,
+    const int32_t *__restrict__ hdrb, const int32_t *__restrict__ segx, int32_t seg_stride,
     const double *__restrict__ dict, const double *__restrict__ x, const double *__restrict__ x_halo,
     int32_t n_local, double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2,
     int xcd_remap) {
@@ -193,40 +191,43 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int64_t nwg = gridDim.x, q = nwg / 8, rm = nwg % 8, xcd = b % 8, idx = b / 8;
     b = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + idx;
   }
-  const int32_t nbatch = cnt[b];
-  const uint8_t *sbase = stream + sb[b];
+  // Everything the block needs first hangs off its index: the 8-dword header, the first pieces of its segment table
+  // (fixed stride per block) and the wave's first two batch descriptors are requested together; the x window, the
+  // dictionary and the first stream words follow after that ONE round trip.
+  const int32_t *hb = hdrb + 8 * b;
+  const int32_t nbatch = hb[0], W = hb[1], nseg = hb[2], nd = hb[3], doff = hb[4];
+  const uint8_t *sbase = stream + (int64_t)(((uint64_t)(uint32_t)hb[6] << 32) | (uint64_t)(uint32_t)hb[5]);
+  const int32_t *sx = segx + 2 * b * (int64_t)seg_stride;
   // Batch descriptors travel through the VECTOR memory path, two batches ahead: lane k of either half-wave holds dword k
   // of a descriptor, the scalars come out of it with v_readlane.  (An s_load one batch ahead, as before, sat in the same
   // lgkmcnt counter as the LDS gathers, and scalar loads return out of order: the first gather wait of every batch also
   // waited for the descriptor of the NEXT one -- a full HBM round trip per batch, the kernel ran at the speed of that.)
   const uint32_t *tb = (const uint32_t *)(tab + (int64_t)b * stride * 16);
   const int hl = lane & 31;
-  auto hdr_load = [&](int32_t q) {   // the block's batch q, clamped to the last one (no branch around a load)
-    const int32_t qq = q < nbatch ? q : (nbatch > 0 ? nbatch - 1 : 0);
+  auto hdr_at = [&](int32_t q) {   // batch q of the block (the table is padded: q may run past the block's last batch)
     uint32_t h4 = 4u * (uint32_t)hl;
     asm volatile("" : "+v"(h4));   // as in vs_shared_fetch: scalar base + 32-bit lane offset
-    return *(const uint32_t *)((const char *)(tb + 32 * (int64_t)qq) + h4);
+    return *(const uint32_t *)((const char *)(tb + 32 * (int64_t)q) + h4);
+  };
+  auto hdr_load = [&](int32_t q) {   // the same, clamped to the block's last batch
+    return hdr_at(q < nbatch ? q : (nbatch > 0 ? nbatch - 1 : 0));
   };
   auto hdr = [](uint32_t hv, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)hv, k); };
-  uint32_t hv1 = hdr_load(wave);
+  uint32_t hv1 = hdr_at(wave);
+  uint32_t hv2 = hdr_at(wave + NW);
   uint32_t w[6];
-  if (wave < nbatch && (int32_t)hdr(hv1, 1) < 0) vs_shared_fetch(hdr(hv1, 0), sbase, lane, w);   // in flight during the block frame
-  uint32_t hv2 = hdr_load(wave + NW);
   {  // block frame: dictionary and x window (segments of at most 64 slots, 4 in flight per wave)
-    const int32_t nd = blk_dict_n[b];
-    for (int t = threadIdx.x; t < nd; t += 64 * NW) ds[t] = dict[blk_dict_off[b] + t];
-    const int32_t W = blk_W[b];
-    const int32_t s0 = blk_seg_begin[b], s1 = blk_seg_begin[b + 1];
     constexpr int U = 4;
-    for (int32_t s = s0 + wave * U; s < s1; s += NW * U) {
+    auto stage = [&](int32_t s) {   // pieces s .. s + U - 1 of the block's window; those past the last are masked
       int32_t c0[U], o0[U], sl[U];
       double v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int32_t q = s + u < s1 ? s + u : s1 - 1;   // wave-uniform; the tail repeats the last segment
-        c0[u] = seg_col[q];
-        o0[u] = seg_off[q];
-        sl[u] = ((q + 1 < s1) ? seg_off[q + 1] : W) - o0[u];
+        const int32_t q = s + u;   // wave-uniform
+        c0[u] = sx[2 * q];
+        o0[u] = sx[2 * q + 1];
+        const int32_t on = sx[2 * q + 3];
+        sl[u] = q < nseg ? ((q + 1 < nseg ? on : W) - o0[u]) : 0;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -236,7 +237,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (lane < sl[u]) xw[o0[u] + lane] = v[u];
-    }
+    };
+    for (int t = threadIdx.x; t < nd; t += 64 * NW) ds[t] = dict[doff + t];
+    if (wave < nbatch && (int32_t)hdr(hv1, 1) < 0) vs_shared_fetch(hdr(hv1, 0), sbase, lane, w);   // in flight during the frame
+    stage(wave * U);   // the first round unconditionally: its table reads do not wait for the header
+    for (int32_t s = (wave + NW) * U; s < nseg; s += NW * U) stage(s);
   }
   __syncthreads();
   // The lane that ends up with a row's tree value stores it.  Which row that is depends on the lane alone --
