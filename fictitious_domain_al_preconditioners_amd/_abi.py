@@ -84,6 +84,7 @@ class MatrixInfo(C.Structure):
         ("dictionary_entries", C.c_int64), ("value_wide_nnz", C.c_int64),
         ("algorithmic_bytes", C.c_double), ("streamed_bytes", C.c_double),
         ("shared_nnz", C.c_int64), ("batch_major_blocks", C.c_int64), ("batch_major_wide", C.c_int64),
+        ("batch_major_interior_blocks", C.c_int64),
     ]
 
 

@@ -116,6 +116,7 @@ struct DevCsr {
     // dependent round trip instead of two (header -> segment table -> x)
     int32_t *hdrb = nullptr, *segx = nullptr;
     int32_t seg_stride = 0;
+    int64_t nb_interior = 0;     // partitioned contexts: the first nb_interior blocks read no halo column
     double *dict = nullptr;
   } vs;
   // bytes the kernel in use moves per launch (format bytes, x read once)
@@ -198,6 +199,9 @@ using namespace alfd;
 struct alfd_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t xstream = nullptr;                  // halo exchanges that run beside the interior row blocks of an SpMV
+  hipEvent_t ev_x = nullptr, ev_halo = nullptr;
+  int overlap_halo = 1;                           // ALFD_SPMV_OVERLAP_HALO
   std::string err;
   // partition / comm
   int rank = 0, nranks = 1;
@@ -382,10 +386,11 @@ static int comm_allgather(alfd_ctx *ctx, const void *send, void *recv, size_t by
 // personalised exchange: rank r sends sendbuf[send_off[p] .. send_off[p+1]) to p and
 // receives recvbuf[recv_off[p] .. recv_off[p+1]) from p (element size `es` bytes)
 static int comm_alltoallv(alfd_ctx *ctx, const void *sendbuf, const int64_t *send_off, void *recvbuf,
-                          const int64_t *recv_off, size_t es) {
+                          const int64_t *recv_off, size_t es, hipStream_t st = nullptr) {
+  if (!st) st = ctx->stream;
   if (ctx->local) {
     alfd_local_group *g = ctx->local;
-    HIPC(hipStreamSynchronize(ctx->stream));
+    HIPC(hipStreamSynchronize(st));
     g->buf[ctx->rank] = sendbuf;
     g->off[ctx->rank] = send_off;
     g->barrier();
@@ -394,9 +399,9 @@ static int comm_alltoallv(alfd_ctx *ctx, const void *sendbuf, const int64_t *sen
       if (nr > 0)  // what p sends to me starts at p's send_off[my rank]
         HIPC(hipMemcpyAsync((char *)recvbuf + (size_t)recv_off[p] * es,
                             (const char *)g->buf[p] + (size_t)g->off[p][ctx->rank] * es, (size_t)nr * es,
-                            hipMemcpyDeviceToDevice, ctx->stream));
+                            hipMemcpyDeviceToDevice, st));
     }
-    HIPC(hipStreamSynchronize(ctx->stream));
+    HIPC(hipStreamSynchronize(st));
     g->barrier();
     return ALFD_OK;
   }
@@ -404,12 +409,12 @@ static int comm_alltoallv(alfd_ctx *ctx, const void *sendbuf, const int64_t *sen
     const size_t ns = (size_t)send_off[ctx->nranks] * es, nr = (size_t)recv_off[ctx->nranks] * es;
     ctx->host_send.resize(std::max<size_t>(ns, 1));
     ctx->host_recv.resize(std::max<size_t>(nr, 1));
-    if (ns) HIPC(hipMemcpyAsync(ctx->host_send.data(), sendbuf, ns, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipStreamSynchronize(ctx->stream));
+    if (ns) HIPC(hipMemcpyAsync(ctx->host_send.data(), sendbuf, ns, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
     if (ctx->host_alltoallv(ctx->host_user, ctx->host_send.data(), send_off, ctx->host_recv.data(), recv_off, es) != 0)
       return ctx->err = "host all-to-all callback failed", ALFD_E_COMM;
-    if (nr) HIPC(hipMemcpyAsync(recvbuf, ctx->host_recv.data(), nr, hipMemcpyHostToDevice, ctx->stream));
-    HIPC(hipStreamSynchronize(ctx->stream));
+    if (nr) HIPC(hipMemcpyAsync(recvbuf, ctx->host_recv.data(), nr, hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));
     return ALFD_OK;
   }
   if (ncclGroupStart() != ncclSuccess) return ctx->err = "ncclGroupStart", ALFD_E_COMM;
@@ -417,11 +422,11 @@ static int comm_alltoallv(alfd_ctx *ctx, const void *sendbuf, const int64_t *sen
   for (int p = 0; p < ctx->nranks && !failed; ++p) {
     const int64_t ns = send_off[p + 1] - send_off[p], nr = recv_off[p + 1] - recv_off[p];
     if (ns > 0 && ncclSend((const char *)sendbuf + (size_t)send_off[p] * es, (size_t)ns * es, ncclChar, p,
-                           ctx->nccl, ctx->stream) != ncclSuccess)
+                           ctx->nccl, st) != ncclSuccess)
       failed = "ncclSend";
     if (!failed && nr > 0 &&
         ncclRecv((char *)recvbuf + (size_t)recv_off[p] * es, (size_t)nr * es, ncclChar, p, ctx->nccl,
-                 ctx->stream) != ncclSuccess)
+                 st) != ncclSuccess)
       failed = "ncclRecv";
   }
   if (ncclGroupEnd() != ncclSuccess && !failed) failed = "ncclGroupEnd";
@@ -706,7 +711,7 @@ static void launch_vss(alfd_ctx *ctx, const DevCsr &m, const double *x, double *
 }
 
 static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y, int epi, double alpha,
-                      const double *d, double *y2) {
+                      const double *d, double *y2, int64_t first_block = 0, int64_t n_blocks = -1) {
   const DevCsr::Vs &v = m.vs;
   if (ctx->vs_lds_base_ok < 0) {   // first batch-major launch of this context: does dynamic LDS start at offset 0?
     uint32_t *probe = nullptr, base = 1;
@@ -726,18 +731,22 @@ static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y
   if (v.L == 8) return launch_vss<8>(ctx, m, x, y, epi, alpha, d, y2), true;
   const int NW = ctx->vs_NW;
   const size_t lds = (size_t)(v.wide ? VsFmt<1>::kWinOff : VsFmt<0>::kWinOff) + (size_t)v.maxW * sizeof(double);
+  if (n_blocks < 0) n_blocks = v.nb - first_block;
+  if (n_blocks <= 0) return true;
+  const unsigned grid = (unsigned)n_blocks;
+  const int32_t base = (int32_t)first_block;
 #define ALFD_VS_ARGS \
-  v.stream, v.tab, v.stride, v.hdrb, v.segx, v.seg_stride, v.dict, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->vs_xcd
+  v.stream, v.tab, v.stride, v.hdrb, v.segx, v.seg_stride, v.dict, x, m.halo, m.n_local_cols, y, alpha, d, y2, ctx->vs_xcd, base
 #define ALFD_VS(EPI, NWV)                                                                                        \
   do {                                                                                                           \
     if (v.wide) /* 10-bit codes: one instantiation per epilogue (4 waves) */                                    \
-      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, 4, 1>), dim3((unsigned)v.nb), dim3(256), lds, ctx->stream,     \
+      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, 4, 1>), dim3(grid), dim3(256), lds, ctx->stream,     \
                          ALFD_VS_ARGS);                                                                          \
     else if (m.tag == 0)                                                                                         \
-      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, NWV>), dim3((unsigned)v.nb), dim3(64 * NWV), lds, ctx->stream, \
+      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 0, NWV>), dim3(grid), dim3(64 * NWV), lds, ctx->stream, \
                          ALFD_VS_ARGS);                                                                          \
     else /* multigrid level matrix: its own instantiation, so that profiles keep the two apart */               \
-      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 1, 4>), dim3((unsigned)v.nb), dim3(256), lds, ctx->stream,        \
+      hipLaunchKernelGGL((spmv_vs_kernel<EPI, 1, 4>), dim3(grid), dim3(256), lds, ctx->stream,        \
                          ALFD_VS_ARGS);                                                                          \
   } while (0)
 #define ALFD_VS_E(NWV)                  \
@@ -756,7 +765,7 @@ static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y
   return true;
 }
 
-static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x);
+static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x, hipStream_t st = nullptr);
 
 // epi 0: y = A x; 1: y = fma(alpha, A x, y); 2: y = d .* (A x); 3: y = A x, y2 = d .* y
 static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y, int epi, double alpha = 0.0,
@@ -764,8 +773,26 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
   if (!m.present) return ctx->err = "matrix not set", ALFD_E_NOT_SETUP;
   // RCCL send/recv pairs can be skipped by ranks with nothing to exchange; the
   // barrier-based in-process group needs every rank in every exchange.
-  if (ctx->nranks > 1 && !m.rep && (ctx->local || ctx->host_alltoallv || m.n_halo > 0 || m.send_off.back() > 0))
-    RC(halo_exchange(ctx, m, x));
+  const bool exchange = ctx->nranks > 1 && !m.rep && (ctx->local || ctx->host_alltoallv || m.n_halo > 0 || m.send_off.back() > 0);
+  // Long-row batch-major operators on a partitioned context: the row blocks that read no halo column come first in the
+  // plan, so they are launched BEFORE the exchange is started (on a stream of its own: pack, send / receive); the
+  // blocks along the partition boundary follow when the halo has arrived.  Row sums do not depend on the order of the
+  // blocks: same bits as the one-launch form.
+  const bool overlap = exchange && ctx->overlap_halo && ctx->xstream && m.vs.on && m.vs.L == 64 && ctx->vs_enable && !ctx->vi_off &&
+                       m.vs.nb_interior > 0 && !m.sparse && m.n_list > 0;
+  if (overlap) {
+    Timer tm(ctx, cls, m.algorithmic_bytes(), m.streamed_bytes(true, true));
+    HIPC(hipEventRecord(ctx->ev_x, ctx->stream));          // x is complete here
+    if (!launch_vs(ctx, m, x, y, epi, alpha, d, y2, 0, m.vs.nb_interior)) return ctx->err = "batch-major launch failed", ALFD_E_HIP;
+    HIPC(hipStreamWaitEvent(ctx->xstream, ctx->ev_x, 0));
+    RC(halo_exchange(ctx, m, x, ctx->xstream));
+    HIPC(hipEventRecord(ctx->ev_halo, ctx->xstream));
+    HIPC(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));
+    launch_vs(ctx, m, x, y, epi, alpha, d, y2, m.vs.nb_interior, m.vs.nb - m.vs.nb_interior);
+    HIPC(hipGetLastError());
+    return ALFD_OK;
+  }
+  if (exchange) RC(halo_exchange(ctx, m, x));
   if (m.sparse && epi != 1) {
     // rows outside the list are structurally empty: their result is 0
     HIPC(hipMemsetAsync(y, 0, m.nrows * sizeof(double), ctx->stream));
@@ -1673,14 +1700,15 @@ static int minres(alfd_ctx *ctx, alfd_result *out) {
 }
 
 // ---------------------------------------------------------------- halo
-static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x) {
+static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x, hipStream_t st) {
+  if (!st) st = ctx->stream;
   const int64_t nsend = m.send_off.back();
   if (nsend > 0) {
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((nsend + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((nsend + 255) / 256)), dim3(256), 0, st,
                        nsend, m.send_idx, x, m.send_buf);
     HIPC(hipGetLastError());
   }
-  RC(comm_alltoallv(ctx, m.send_buf, m.send_off.data(), m.halo, m.recv_off.data(), sizeof(double)));
+  RC(comm_alltoallv(ctx, m.send_buf, m.send_off.data(), m.halo, m.recv_off.data(), sizeof(double), st));
   return ALFD_OK;
 }
 
@@ -2031,7 +2059,7 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
 // kVsMaxLen entries; otherwise the matrix keeps the formats of plan_window.
 struct VsPlan {
   bool ok = false;
-  int64_t nb = 0, nbatch = 0, shared_nnz = 0;
+  int64_t nb = 0, nbatch = 0, shared_nnz = 0, nb_interior = 0;
   int rbs = 0, stride = 0;
   int32_t maxW = 0;
   std::vector<int32_t> blkW, seg_begin, seg_col, seg_off, doff, dn, cnt;
@@ -2284,7 +2312,7 @@ static bool vs_refine_blocks(int64_t nrows, const int64_t *rp, const double *val
 
 static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const double *val, int RB, int maxW,
                     int GAP, int64_t nb_in, const int64_t *bptr_in, const int32_t *brows_in, VsPlan &pl,
-                    bool share = true, int wide = 0) {
+                    bool share = true, int wide = 0, int64_t n_local_cols = -1) {
   std::vector<int64_t> r_ptr;
   std::vector<int32_t> r_rows;
   const int max_dict = wide ? VsFmt<1>::kMaxDict : VsFmt<0>::kMaxDict, code_shift = wide ? VsFmt<1>::kCodeShift : VsFmt<0>::kCodeShift;
@@ -2292,6 +2320,28 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
   pl.wide = wide;
   pl.nb_in = nb_in > 0 ? nb_in : (nrows + RB - 1) / RB;
   if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, nb_in, bptr_in, brows_in, r_ptr, r_rows, kVsMaxRows, max_dict)) return;
+  if (n_local_cols >= 0) {
+    // partitioned operator: the blocks that read no halo column (columns >= n_local_cols) first, so that they can run
+    // while the halo is still on its way (spmv_m); the order of the blocks is free, every row names its own result
+    const int64_t nb0 = (int64_t)r_ptr.size() - 1;
+    std::vector<uint8_t> bnd(nb0, 0);
+    for (int64_t b = 0; b < nb0; ++b)
+      for (int64_t i = r_ptr[b]; i < r_ptr[b + 1] && !bnd[b]; ++i) {
+        const int32_t r = r_rows[i];
+        for (int64_t k = rp[r]; k < rp[r + 1] && !bnd[b]; ++k) bnd[b] = col[k] >= n_local_cols;   // halo columns sit anywhere in a row
+      }
+    std::vector<int64_t> np(1, 0);
+    std::vector<int32_t> nr;
+    nr.reserve(r_rows.size());
+    for (int pass = 0; pass < 2; ++pass)
+      for (int64_t b = 0; b < nb0; ++b)
+        if (bnd[b] == pass) {
+          nr.insert(nr.end(), r_rows.begin() + r_ptr[b], r_rows.begin() + r_ptr[b + 1]);
+          np.push_back((int64_t)nr.size());
+        }
+    r_ptr.swap(np);
+    r_rows.swap(nr);
+  }
   const int T = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::vector<VsBatch>> batches;
   std::vector<int64_t> blk_units;
@@ -2412,6 +2462,17 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
   }
   if (bad) return;
   pl.nb = nb;
+  pl.nb_interior = 0;
+  if (n_local_cols >= 0) {   // leading blocks without a halo column (splits for the window keep the order)
+    bool interior = true;
+    for (int64_t b = 0; b < nb && interior; ++b) {
+      for (int64_t i = bptr[b]; i < bptr[b + 1] && interior; ++i) {
+        const int32_t r = brows[i];
+        for (int64_t k = rp[r]; k < rp[r + 1] && interior; ++k) interior = col[k] < n_local_cols;
+      }
+      if (interior) pl.nb_interior = b + 1;
+    }
+  }
   pl.shared_nnz = n_shared_nnz;
   pl.sb.assign(nb, 0);
   int64_t tot = 0;
@@ -2738,6 +2799,7 @@ static void plan_vss(int64_t nrows, int L, const int64_t *rp, const int32_t *col
 
 static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const int32_t *col, const double *val) {
   VsPlan pl;
+  const int64_t nlc = (ctx->nranks > 1 && !m.rep) ? (int64_t)m.n_local_cols : -1;   // columns >= nlc are halo columns
   bool hint = slot >= 0 && slot < ALFD_NSLOTS && !ctx->rb_ptr[slot].empty();
   if (hint && ctx->rb_ptr[slot].back() != m.nrows) {
     // the hint was given for a matrix of another size (a re-upload of the slot): it no longer applies
@@ -2761,9 +2823,9 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
     for (size_t i = 0; good && i + 1 < bp.size(); ++i) good = bp[i] <= bp[i + 1];
     if (!good) return ctx->err = "alfd_set_row_blocks: the blocks are not a partition of the matrix rows", ALFD_E_INVALID;
     plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, (int64_t)bp.size() - 1, bp.data(),
-            br.data(), pl, ctx->vs_share != 0);
+            br.data(), pl, ctx->vs_share != 0, 0, nlc);
   } else {
-    plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pl, ctx->vs_share != 0);
+    plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pl, ctx->vs_share != 0, 0, nlc);
   }
   if (ctx->vs_wide && (!pl.ok || pl.nb > pl.nb_in)) {
     // blocks with more than 512 distinct values had to be halved (or the plan failed): the same blocks with 10-bit
@@ -2771,9 +2833,9 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
     VsPlan pw;
     if (hint)
       plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, (int64_t)ctx->rb_ptr[slot].size() - 1,
-              ctx->rb_ptr[slot].data(), ctx->rb_rows[slot].data(), pw, ctx->vs_share != 0, 1);
+              ctx->rb_ptr[slot].data(), ctx->rb_rows[slot].data(), pw, ctx->vs_share != 0, 1, nlc);
     else
-      plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pw, ctx->vs_share != 0, 1);
+      plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pw, ctx->vs_share != 0, 1, nlc);
     if (pw.ok && (!pl.ok || pw.stream.size() + 128 * (size_t)pw.nbatch < pl.stream.size() + 128 * (size_t)pl.nbatch)) pl = std::move(pw);
   }
   if (!pl.ok) return ALFD_OK;
@@ -2808,6 +2870,7 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
   RC(upload_vec(ctx, m, &v.dict, pl.dict));
   HIPC(hipStreamSynchronize(ctx->stream));
   v.seg_stride = S;
+  v.nb_interior = pl.nb_interior;
   v.nb = pl.nb;
   v.nseg = (int64_t)pl.seg_col.size();
   v.stream_bytes = (int64_t)pl.stream.size() - 4096;
@@ -5213,6 +5276,11 @@ int alfd_create(alfd_ctx_t *out, int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return ALFD_E_HIP;
   alfd_ctx *ctx = new alfd_ctx;
   ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->xstream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming) != hipSuccess)
+    ctx->xstream = nullptr;   // no overlap then
+  if (const char *e = std::getenv("ALFD_SPMV_OVERLAP_HALO")) ctx->overlap_halo = std::atoi(e);
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return ALFD_E_HIP;
@@ -5261,6 +5329,9 @@ int alfd_destroy(alfd_ctx_t ctx) {
   if (ctx->n_sc_host) hipHostFree(ctx->n_sc_host);
   if (ctx->rt_scb_host) hipHostFree(ctx->rt_scb_host);
   if (ctx->nccl) ncclCommDestroy(ctx->nccl);
+  if (ctx->xstream) hipStreamDestroy(ctx->xstream);
+  if (ctx->ev_x) hipEventDestroy(ctx->ev_x);
+  if (ctx->ev_halo) hipEventDestroy(ctx->ev_halo);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return ALFD_OK;
@@ -5900,6 +5971,7 @@ int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out) {
   out->shared_nnz = m.vs.on ? m.vs.shared_nnz : 0;
   out->batch_major_blocks = m.vs.on ? m.vs.nb : 0;
   out->batch_major_wide = m.vs.on ? m.vs.wide : 0;
+  out->batch_major_interior_blocks = (m.vs.on && m.vs.L == 64 && ctx->nranks > 1 && !m.rep) ? m.vs.nb_interior : 0;
   return ALFD_OK;
 }
 

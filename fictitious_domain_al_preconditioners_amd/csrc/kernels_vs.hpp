@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int32_t *__restrict__ hdrb, const int32_t *__restrict__ segx, int32_t seg_stride,
     const double *__restrict__ dict, const double *__restrict__ x, const double *__restrict__ x_halo,
     int32_t n_local, double *__restrict__ y, double alpha, const double *__restrict__ d, double *__restrict__ y2,
-    int xcd_remap) {
+    int xcd_remap, int32_t block_base) {
   extern __shared__ double xs[];
   char *sm = (char *)xs;
   double *ds = (double *)(sm + kVsDictOff);
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int64_t nwg = gridDim.x, q = nwg / 8, rm = nwg % 8, xcd = b % 8, idx = b / 8;
     b = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + idx;
   }
+  b += block_base;   // a launch covers the blocks block_base .. block_base + gridDim.x - 1 (interior / boundary halves)
   // Everything the block needs first hangs off its index: the 8-dword header, the first pieces of its segment table
   // (fixed stride per block) and the wave's first two batch descriptors are requested together; the x window, the
   // dictionary and the first stream words follow after that ONE round trip.

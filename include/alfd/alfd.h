@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALFD_ABI_VERSION 11
+#define ALFD_ABI_VERSION 12
 #define ALFD_MAX_BLOCKS 3
 
 /* ------------------------------------------------------------------ status */
@@ -403,6 +403,8 @@ typedef struct alfd_matrix_info {
   int64_t shared_nnz;    /* batch-major forms: entries of rows stored as translates of a template row */
   int64_t batch_major_blocks;
   int64_t batch_major_wide;  /* 1: 10-bit dictionary codes / 11-bit window columns (blocks with > 512 distinct values) */
+  int64_t batch_major_interior_blocks; /* partitioned contexts: leading row blocks that read no halo column -- launched
+                                        * before the halo exchange is started (the rest after it has arrived); else 0 */
 } alfd_matrix_info;
 int alfd_get_matrix_info(alfd_ctx_t ctx, int slot, alfd_matrix_info *out);
 /* Host-only (no device, no context): plans the LDS-window / value-indexed storage of

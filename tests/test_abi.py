@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_version_strerror_and_default_config_mirror():
     lib = solver.load_library()
-    assert lib.alfd_abi_version() == 11
+    assert lib.alfd_abi_version() == 12
     assert b"NoConvergence" in lib.alfd_strerror(_abi.E_NO_CONVERGENCE_INNER)
     assert lib.alfd_strerror(_abi.OK) == b"ok"
     for variant in (_abi.AL2, _abi.AL_STOKES, _abi.AL_ELL_MODIFIED, _abi.RATIONAL):
@@ -46,7 +46,7 @@ def test_version_strerror_and_default_config_mirror():
     assert (c.restart, c.inner.max_steps, c.inner.tol, c.inner.kind) == (30, 100, 1e-2, _abi.CTRL_ABS)
     assert _abi.default_config(_abi.AL_ELL_MODIFIED).restart == 50
     assert C.sizeof(_abi.Config) == 264 and C.sizeof(_abi.Result) == 80
-    assert C.sizeof(_abi.MatrixInfo) == 112 and C.sizeof(_abi.WindowPlanInfo) == 88
+    assert C.sizeof(_abi.MatrixInfo) == 120 and C.sizeof(_abi.WindowPlanInfo) == 88
 
 
 def test_argument_validation_without_gpu():
