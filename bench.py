@@ -161,15 +161,32 @@ def main():
     cfg.inner.max_steps = args.inner_max
     min_coarse = args.min_coarse if args.min_coarse is not None else (_abi.BENCH_MIN_COARSE if geometric else 4000)
 
+    rccl_fallback = False
     t0 = time.time()
     ctx = solver.Context(local_rank)
     if world > 1:
         if args.comm == "host":
             ctx.comm_init_torch(dist.group.WORLD)
         else:
-            uid = [solver.Context.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(rank, world, uid[0])
+            # RCCL inside the library.  If it cannot be brought up on ANY rank (the library links the system's librccl, torch
+            # ships its own copy; this path has not run on hardware yet), every rank falls back to the host transport
+            # rather than leaving the line empty; config.transport says which one ran.
+            ok = True
+            try:
+                uid = [solver.Context.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init(rank, world, uid[0])
+            except Exception as e:   # noqa: BLE001
+                ok = False
+                log(f"RCCL initialisation failed on rank {rank}: {e!r}")
+            flags = [None] * world
+            dist.all_gather_object(flags, ok)
+            if not all(flags):
+                ctx.close()
+                ctx = solver.Context(local_rank)
+                ctx.comm_init_torch(dist.group.WORLD)
+                args.comm = "host"
+                rccl_fallback = True
         ctx.set_partition(plan.offsets)
     ta = time.time()
     overlapped = {}
@@ -390,7 +407,8 @@ def main():
             "inner_prec": prec_name(),
             "inner_max_steps": cfg.inner.max_steps,
             "restart": cfg.restart, "partition": f"row-slabs x{world}",
-            "transport": ("rccl" if args.comm == "rccl" else "host buffers over gloo") if world > 1 else None,
+            "transport": ("rccl" if args.comm == "rccl" else
+                          "host buffers over gloo" + (" (RCCL could not be initialised)" if rccl_fallback else "")) if world > 1 else None,
         },
         # setup in the record: the reference solves ONCE per run and its "Solve system" timer includes AMG setup and
         # factorisations (stokes_immersed_boundary.cc:827); value above is the Krylov loop with resident operators

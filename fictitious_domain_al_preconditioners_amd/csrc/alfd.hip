@@ -201,7 +201,9 @@ struct alfd_ctx {
   hipStream_t stream = nullptr;
   hipStream_t xstream = nullptr;                  // halo exchanges that run beside the interior row blocks of an SpMV
   hipEvent_t ev_x = nullptr, ev_halo = nullptr;
-  int overlap_halo = 1;                           // ALFD_SPMV_OVERLAP_HALO
+  int overlap_halo = -1;                          // ALFD_SPMV_OVERLAP_HALO: 1 on, 0 off, -1 (default): on for the in-process and
+                                                  // host transports, off over RCCL until that path has run on hardware once
+                                                  // (one communicator driven from two streams)
   std::string err;
   // partition / comm
   int rank = 0, nranks = 1;
@@ -778,7 +780,7 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
   // plan, so they are launched BEFORE the exchange is started (on a stream of its own: pack, send / receive); the
   // blocks along the partition boundary follow when the halo has arrived.  Row sums do not depend on the order of the
   // blocks: same bits as the one-launch form.
-  const bool overlap = exchange && ctx->overlap_halo && ctx->xstream && m.vs.on && m.vs.L == 64 && ctx->vs_enable && !ctx->vi_off &&
+  const bool overlap = exchange && (ctx->overlap_halo > 0 || (ctx->overlap_halo < 0 && (ctx->local || ctx->host_alltoallv))) && ctx->xstream && m.vs.on && m.vs.L == 64 && ctx->vs_enable && !ctx->vi_off &&
                        m.vs.nb_interior > 0 && !m.sparse && m.n_list > 0;
   if (overlap) {
     Timer tm(ctx, cls, m.algorithmic_bytes(), m.streamed_bytes(true, true));
