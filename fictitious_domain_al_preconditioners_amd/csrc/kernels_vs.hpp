@@ -22,6 +22,11 @@
 //        one dictionary gather serves all rows.  96 % of the entries of the Stokes velocity block;
 //    of the last, partial chunk only the lanes below the batch's longest remainder are stored;
 //  * the 128-byte batch descriptor names the GLOBAL row of each row, so the sums go straight to y.
+//  * per block an 8-dword header {batches, window slots, window pieces, dictionary size, dictionary offset, stream offset
+//    lo / hi, 0} and a segment table with a fixed stride per block ((column, slot) pairs): both addressable from the block
+//    index alone, so the x window is requested after one dependent round trip; a launch covers the blocks
+//    block_base .. block_base + gridDim.x - 1 (partitioned contexts launch the blocks without halo columns first and the
+//    rest when the halo has arrived).
 //
 // At N = 74: 0.445 ms per launch (round 2: 0.52 ms with 8-row batches; round-1 kernel: 6.08 GB, 1.5 ms).  The time is
 // t = 2.6 ms / (waves per SIMD) + 0.19 ms (measured by padding the LDS request): what counts is the serial length of
