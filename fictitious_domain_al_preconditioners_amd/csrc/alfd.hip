@@ -2062,6 +2062,7 @@ static int build_window(alfd_ctx *ctx, DevCsr &m, const int64_t *rp, const int32
 struct VsPlan {
   bool ok = false;
   int64_t nb = 0, nbatch = 0, shared_nnz = 0, nb_interior = 0;
+  bool dict_split = false;   // blocks were halved for their dictionaries (or row counts): wide codes may pay
   int rbs = 0, stride = 0;
   int32_t maxW = 0;
   std::vector<int32_t> blkW, seg_begin, seg_col, seg_off, doff, dn, cnt;
@@ -2322,6 +2323,7 @@ static void plan_vs(int64_t nrows, const int64_t *rp, const int32_t *col, const 
   pl.wide = wide;
   pl.nb_in = nb_in > 0 ? nb_in : (nrows + RB - 1) / RB;
   if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, nb_in, bptr_in, brows_in, r_ptr, r_rows, kVsMaxRows, max_dict)) return;
+  pl.dict_split = (int64_t)r_ptr.size() - 1 > pl.nb_in;
   if (n_local_cols >= 0) {
     // partitioned operator: the blocks that read no halo column (columns >= n_local_cols) first, so that they can run
     // while the halo is still on its way (spmv_m); the order of the blocks is free, every row names its own result
@@ -2829,7 +2831,7 @@ static int build_vs(alfd_ctx *ctx, DevCsr &m, int slot, const int64_t *rp, const
   } else {
     plan_vs(m.nrows, rp, col, val, ctx->vs_RB, ctx->win_maxW, ctx->win_gap, 0, nullptr, nullptr, pl, ctx->vs_share != 0, 0, nlc);
   }
-  if (ctx->vs_wide && (!pl.ok || pl.nb > pl.nb_in)) {
+  if (ctx->vs_wide && (!pl.ok || pl.dict_split)) {
     // blocks with more than 512 distinct values had to be halved (or the plan failed): the same blocks with 10-bit
     // codes and 11-bit window columns, kept if the stream gets smaller
     VsPlan pw;
@@ -6116,7 +6118,7 @@ int alfd_host_stream_plan(int64_t nrows, const int64_t *rp, const int32_t *col, 
   VsPlan pl;
   if (n_blocks > 0) plan_vs(nrows, rp, col, val, row_block, 4096, 8, n_blocks, block_ptr, rows, pl);
   else plan_vs(nrows, rp, col, val, row_block, 4096, 8, 0, nullptr, nullptr, pl);
-  if (!pl.ok || pl.nb > pl.nb_in) {   // as build_vs: wide codes when the 512-value limit halved blocks
+  if (!pl.ok || pl.dict_split) {   // as build_vs: wide codes when the 512-value limit halved blocks
     VsPlan pw;
     if (n_blocks > 0) plan_vs(nrows, rp, col, val, row_block, 4096, 8, n_blocks, block_ptr, rows, pw, true, 1);
     else plan_vs(nrows, rp, col, val, row_block, 4096, 8, 0, nullptr, nullptr, pw, true, 1);
