@@ -320,7 +320,7 @@ struct alfd_ctx {
   std::vector<int64_t> rb_ptr[ALFD_NSLOTS + 1];   // row-block hint per slot (alfd_set_row_blocks)
   std::vector<int32_t> rb_rows[ALFD_NSLOTS + 1];
   int win_short_min_blocks = 256;           // the same for short-row matrices (ALFD_SPMV_WINDOW_SHORT_MIN_BLOCKS; 64 costs cfg 3 30 %, 1024 leaves its 262 k-row level operator out)
-  int win_min_blocks = 512;                 // long-row window formats need this many row blocks (ALFD_SPMV_WINDOW_MIN_BLOCKS; 2 per CU: the level-2 operator of the bench, 152 k rows, gains 2 % of the solve)
+  int win_min_blocks = 256;                 // long-row window formats need this many row blocks (ALFD_SPMV_WINDOW_MIN_BLOCKS; 1 per CU: the level-2 operator of the bench, 152 k rows, gains 2 % of the solve, the 36.7 k-row patch matrix another 1 %; 128: slower)
   int win_enable = 1, win_RB = 96, win_maxW = 4096, win_gap = 8, win_xcd = 0;  // win_xcd: XCD-contiguous block order (measured neutral on MI355X)
   int64_t ntot() const { return off[nblocks]; }
 };
