@@ -238,11 +238,14 @@ def test_rank_without_multiplier_rows(built):
         assert np.allclose(xs, ox[b], rtol=1e-9, atol=1e-10 * max(np.abs(ox[b]).max(), 1e-30))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_batch_major_spmv_bitwise(built, world):
-    """The A-SpMV of a partition large enough for the LDS-window / batch-major formats (>= 512 row blocks per
+@pytest.mark.parametrize("world,overlap", [(2, None), (3, None), (2, "0")])
+def test_partitioned_batch_major_spmv_bitwise(built, world, overlap, monkeypatch):
+    """The A-SpMV of a partition large enough for the LDS-window / batch-major formats (>= 256 row blocks per
     rank; the solves above are too small for them): halo columns inside the staged x windows, mesh-brick row
-    blocks per rank.  Every rank's rows must equal the unpartitioned product bit for bit."""
+    blocks per rank.  Every rank's rows must equal the unpartitioned product bit for bit -- with the halo exchange
+    running beside the interior row blocks (the default on this transport) and with ALFD_SPMV_OVERLAP_HALO=0."""
+    if overlap is not None:
+        monkeypatch.setenv("ALFD_SPMV_OVERLAP_HALO", overlap)     # read when a context is created
     n, ref = 28 + 8 * (world - 2), 0
     plan = partition.slab_partition_stokes3d(n, ref, world)
     full = problems.stokes3d_sphere(n, ref)
