@@ -768,6 +768,8 @@ static bool launch_vs(alfd_ctx *ctx, const DevCsr &m, const double *x, double *y
 }
 
 static int halo_exchange(alfd_ctx *ctx, DevCsr &m, const double *x, hipStream_t st = nullptr);
+static int spmv_launch_local(alfd_ctx *ctx, DevCsr &m, const double *x, double *y, int epi, double alpha, const double *d,
+                             double *y2);
 
 // epi 0: y = A x; 1: y = fma(alpha, A x, y); 2: y = d .* (A x); 3: y = A x, y2 = d .* y
 static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y, int epi, double alpha = 0.0,
@@ -802,6 +804,12 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
   }
   if (m.n_list == 0) return ALFD_OK;
   Timer tm(ctx, cls, m.algorithmic_bytes(), m.streamed_bytes(!ctx->vi_off, ctx->vs_enable != 0 && !ctx->vi_off));
+  return spmv_launch_local(ctx, m, x, y, epi, alpha, d, y2);
+}
+
+// the kernel of the storage form in use, on this rank's rows (halo already in place)
+static int spmv_launch_local(alfd_ctx *ctx, DevCsr &m, const double *x, double *y, int epi, double alpha, const double *d,
+                             double *y2) {
   if (m.vs.on && ctx->vs_enable && !ctx->vi_off && launch_vs(ctx, m, x, y, epi, alpha, d, y2)) {   // vi_off: alfd_bench_spmv_format(…, 0)
     HIPC(hipGetLastError());
     return ALFD_OK;
@@ -835,7 +843,7 @@ static int spmv_m(alfd_ctx *ctx, DevCsr &m, int cls, const double *x, double *y,
 // 0.44 ms).  Large operators are therefore timed once at upload, five launches of each on a zero vector, and keep the
 // faster form; results do not depend on the choice (same canonical sums).
 static int pick_short_row_format(alfd_ctx *ctx, DevCsr &m) {
-  if (!m.vs.on || m.vs.L == 64 || !m.win || m.nnz < 20000000 || ctx->vi_off || !ctx->vs_enable) return ALFD_OK;
+  if (!m.vs.on || m.vs.L == 64 || m.nnz < 20000000 || ctx->vi_off || !ctx->vs_enable || m.sparse) return ALFD_OK;
   double *x = nullptr, *y = nullptr;
   const int64_t nx = std::max<int64_t>(ctx->nranks > 1 && !m.rep ? m.n_local_cols : m.ncols, 1);
   HIPC(hipMalloc((void **)&x, nx * sizeof(double)));
@@ -849,8 +857,10 @@ static int pick_short_row_format(alfd_ctx *ctx, DevCsr &m) {
   for (int f = 0; f < 2 && ok; ++f) {
     for (int it = 0; it < 6 && ok; ++it) {   // the first launch of each form is a warm-up
       if (it == 1) hipEventRecord(e0, ctx->stream);
-      ok = f == 0 ? launch_vs(ctx, m, x, y, 0, 0.0, nullptr, nullptr) : launch_window_RU(ctx, m, x, y, 0, 0.0, nullptr, nullptr);
+      m.vs.on = f == 0;   // f = 1: whatever the operator runs on without the batch-major form
+      ok = spmv_launch_local(ctx, m, x, y, 0, 0.0, nullptr, nullptr) == ALFD_OK;
     }
+    m.vs.on = true;
     hipEventRecord(e1, ctx->stream);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&t[f], e0, e1);
@@ -863,7 +873,7 @@ static int pick_short_row_format(alfd_ctx *ctx, DevCsr &m) {
   if (ok && t[1] < 0.9f * t[0]) {
     m.vs.on = false;
     if (ctx->cfg.log_level > 0 || std::getenv("ALFD_LOG_UPLOAD"))
-      std::fprintf(stderr, "[alfd] short-row operator (%lld rows, %lld nnz): windowed group kernel %.3f ms, batch-major %.3f ms per launch "
+      std::fprintf(stderr, "[alfd] short-row operator (%lld rows, %lld nnz): without the batch-major form %.3f ms, with it %.3f ms per launch "
                    "-> batch-major form dropped\n", (long long)m.nrows, (long long)m.nnz, t[1] / 5.0, t[0] / 5.0);
   }
   return ALFD_OK;
@@ -2614,6 +2624,32 @@ static void plan_vss(int64_t nrows, int L, const int64_t *rp, const int32_t *col
   std::vector<int64_t> r_ptr;
   std::vector<int32_t> r_rows;
   if (nrows == 0 || !vs_refine_blocks(nrows, rp, val, RB, 0, nullptr, nullptr, r_ptr, r_rows, kVssMaxRows)) return;
+  {
+    // blocks whose x window would not fit (operators whose rows reach far: the restriction from the Q2 grid, 384 coarse
+    // rows touch 7 000 fine columns): how often do three sample blocks have to be halved?  Every block is split that often.
+    int k = 0;
+    std::vector<int32_t> rows;
+    VsWindow w;
+    const int64_t nb0 = (int64_t)r_ptr.size() - 1;
+    for (int64_t b : {(int64_t)0, nb0 / 2, nb0 - 1}) {
+      int64_t len = r_ptr[b + 1] - r_ptr[b];
+      int kb = 0;
+      for (; len > 1; ++kb, len = (len + 1) / 2) {
+        rows.assign(r_rows.begin() + r_ptr[b], r_rows.begin() + r_ptr[b] + len);
+        if (vs_window(rows, rp, col, GAP, maxW, w, nullptr, nullptr)) break;
+      }
+      k = std::max(k, kb);
+    }
+    if (k > 0) {
+      std::vector<int64_t> np(1, 0);
+      for (int64_t b = 0; b < nb0; ++b) {
+        const int64_t a = r_ptr[b], len = r_ptr[b + 1] - a, pieces = std::min<int64_t>((int64_t)1 << k, std::max<int64_t>(len, 1));
+        for (int64_t q = 1; q <= pieces; ++q)
+          if (a + len * q / pieces > np.back()) np.push_back(a + len * q / pieces);
+      }
+      r_ptr.swap(np);
+    }
+  }
   const int64_t *bptr = r_ptr.data();
   const int32_t *brows = r_rows.data();
   const int64_t nb = (int64_t)r_ptr.size() - 1;
@@ -3102,7 +3138,9 @@ static int upload_matrix(alfd_ctx *ctx, int slot, int64_t nrows, int64_t ncols, 
                  (long long)m.nnz, std::chrono::duration<double>(t_plan0 - t_up0).count(),
                  std::chrono::duration<double>(t_plan1 - t_plan0).count(),
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t_plan1).count());
-  if (ctx->vs_enable && m.win && (m.L == 32 || m.L == 16 || m.L == 8)) RC(build_vss(ctx, m, rp, col_up, val));
+  // (also when the 10 B/nnz window plan did not fit its row blocks: plan_vss halves blocks whose x window is too wide --
+  // transfer operators, whose rows reach across two grids)
+  if (ctx->vs_enable && windows && !m.sparse && (m.L == 32 || m.L == 16 || m.L == 8)) RC(build_vss(ctx, m, rp, col_up, val));
   if (copy_job.th.joinable()) {
     copy_job.th.join();
     if (copy_job.rc != hipSuccess) return ctx->err = hipGetErrorString(copy_job.rc), ALFD_E_HIP;
